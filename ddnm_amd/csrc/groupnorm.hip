@@ -1,0 +1,124 @@
+// GroupNorm statistics for NHWC activations, gfx950.  HBM-bound: one coalesced read of the
+// tensor (float4 per lane along C), fp32 partial sums over <= 64 pixels per thread, then
+// fp64 combination in a fixed order (deterministic, no atomics).  The normalisation itself
+// is never materialised: `finalize` emits a per-(sample, channel) affine that the consumer
+// convolution applies while it stages its A tile (conv_igemm_f32.hip).
+// Replaces torch.nn.GroupNorm(32, C, eps) -- guided_diffusion/models.py:32-33,
+// guided_diffusion/nn.py:17-19,93-100.
+#include "common.h"
+
+constexpr int GN_PIX_PER_THREAD = 64;
+
+static inline int gn_block_dim(int C4) { return C4 <= 256 ? 256 : (C4 <= 512 ? 512 : 1024); }
+
+extern "C" int ddnm_gn_nchunk(int32_t HW, int32_t C) {
+    const int C4 = C / 4;
+    if (C4 <= 0 || C4 > 1024) return DDNM_E_SHAPE;
+    const int rows = gn_block_dim(C4) / C4;
+    const int pix = rows * GN_PIX_PER_THREAD;
+    return (HW + pix - 1) / pix;
+}
+
+__global__ void gn_stats_kernel(const float* __restrict__ src0, const float* __restrict__ src1, int HW, int C0,
+                                int C1, int groups, double* __restrict__ partial, int nchunk, int pix_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // [2][blockDim]
+    const int C = C0 + C1, C4 = C >> 2;
+    const int rows = blockDim.x / C4, active = rows * C4;
+    const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
+    float s = 0.f, ss = 0.f;
+    if (tid < active) {
+        const int c4 = tid % C4, prow = tid / C4;
+        const int c = c4 * 4;
+        const float* base;
+        int cs;
+        if (c < C0) { base = src0 + (size_t)b * HW * C0 + c; cs = C0; }
+        else { base = src1 + (size_t)b * HW * C1 + (c - C0); cs = C1; }
+        const int p_end = min(HW, (chunk + 1) * pix_per_chunk);
+        for (int p = chunk * pix_per_chunk + prow; p < p_end; p += rows) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * cs);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    }
+    red[tid] = (double)s;
+    red[blockDim.x + tid] = (double)ss;
+    __syncthreads();
+    if (tid < groups) {
+        const int q = (C / groups) >> 2;            // float4 columns per group
+        double a = 0.0, a2 = 0.0;
+        for (int r = 0; r < rows; ++r)
+            for (int j = 0; j < q; ++j) {
+                const int t = r * C4 + tid * q + j;
+                a += red[t];
+                a2 += red[blockDim.x + t];
+            }
+        double* o = partial + (((size_t)b * nchunk + chunk) * groups + tid) * 2;
+        o[0] = a;
+        o[1] = a2;
+    }
+}
+
+extern "C" int ddnm_gn_stats_f32(const float* src0, const float* src1, int32_t B, int32_t HW, int32_t C0, int32_t C1,
+                                 int32_t groups, double* partial, int32_t nchunk, void* stream) {
+    if (!src0 || !partial || B <= 0 || HW <= 0 || C0 <= 0 || (C1 > 0 && !src1)) return DDNM_E_BADARG;
+    const int C = C0 + C1;
+    if (groups <= 0 || groups > 64 || C % (groups * 4) || C0 % 4 || C / 4 > 1024) return DDNM_E_SHAPE;
+    const int C4 = C / 4, bd = gn_block_dim(C4);
+    const int rows = bd / C4, pix = rows * GN_PIX_PER_THREAD;
+    if (nchunk != (HW + pix - 1) / pix) return DDNM_E_BADARG;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), (hipStream_t)stream, src0,
+                       src1, HW, C0, C1, groups, partial, nchunk, pix);
+    DDNM_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int nchunk,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int HW, int C, int groups,
+                                                          float eps, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+    __shared__ double acc[64][4][2];
+    __shared__ float mean_s[64], rstd_s[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g = tid >> 2, sub = tid & 3;            // 64 groups x 4 partial lanes
+    if (g < groups) {
+        double a = 0.0, a2 = 0.0;
+        for (int ch = sub; ch < nchunk; ch += 4) {
+            const double* p = partial + (((size_t)b * nchunk + ch) * groups + g) * 2;
+            a += p[0];
+            a2 += p[1];
+        }
+        acc[g][sub][0] = a;
+        acc[g][sub][1] = a2;
+    }
+    __syncthreads();
+    if (g < groups && sub == 0) {
+        const double a = (acc[g][0][0] + acc[g][1][0]) + (acc[g][2][0] + acc[g][3][0]);
+        const double a2 = (acc[g][0][1] + acc[g][1][1]) + (acc[g][2][1] + acc[g][3][1]);
+        const double cnt = (double)HW * (double)(C / groups);
+        const double mean = a / cnt;
+        double var = a2 / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mean_s[g] = (float)mean;
+        rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int c = tid; c < C; c += 256) {
+        const int gg = c / cpg;
+        const float sc = rstd_s[gg] * gamma[c];
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = beta[c] - mean_s[gg] * sc;
+    }
+}
+
+extern "C" int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gamma, const float* beta,
+                                    int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, float* scale,
+                                    float* shift, void* stream) {
+    if (!partial || !gamma || !beta || !scale || !shift || B <= 0 || nchunk <= 0) return DDNM_E_BADARG;
+    if (groups <= 0 || groups > 64 || C % groups) return DDNM_E_SHAPE;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, gamma, beta,
+                       HW, C, groups, eps, scale, shift);
+    DDNM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,200 @@
+/*
+ * ddnm_hip.h -- C ABI of libddnm_hip.so: hand-written HIP kernels (gfx950 / CDNA4)
+ * for the DDNM sampling hot path.
+ *
+ * The reference (wyhuai/DDNM) has no FFI of its own: it is pure PyTorch and every
+ * hot op is an ATen call.  Each entry point below replaces
+ * the ATen call sites cited next to it; INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no torch types, no allocation, no host sync,
+ *     no global state; work is enqueued on `stream` (hipStream_t passed as void*).
+ *   - returns 0 on success, a positive hipError_t on a runtime error, or a negative
+ *     DDNM_E_* code on an argument the kernel family does not support.
+ *   - activations inside the UNet are NHWC fp32 ("pixel-major": [B][H][W][C]);
+ *     the sampler-side images are NCHW fp32 exactly like the reference tensors.
+ *   - thread-safe for concurrent calls on different streams / devices.
+ */
+#ifndef DDNM_HIP_H
+#define DDNM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
+#define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
+
+int ddnm_version(void);                 /* ABI version, currently 1 */
+const char* ddnm_error_string(int code);
+
+/* ------------------------------------------------------------------------- *
+ * Implicit-GEMM convolution, fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ * Replaces nn.Conv2d 3x3 s1 p1 (guided_diffusion/models.py:87,96,225,295),
+ * the asymmetric-pad 3x3 s2 Downsample (models.py:61-71), 1x1 convs
+ * (models.py:109,143-162) and, through the fused prologue/epilogue, the
+ * GroupNorm+swish in front of each conv (models.py:117-118,123-124,166,338-339),
+ * F.interpolate(nearest x2) (models.py:48), torch.cat([h, skip]) (models.py:331),
+ * the temb add (models.py:121) and the residual add (models.py:134,189).
+ *
+ *   out[b,oy,ox,n] = bias[n] + badd[b*badd_stride + n] + res[b,oy,ox,n]
+ *                  + sum_{ky,kx,c} W[n,ky,kx,c] * act(in[b, oy*stride-pad+ky, ox*stride-pad+kx, c])
+ *   in  = concat_c(src0 (C0 ch), src1 (C1 ch)), optionally nearest-x2 upsampled (ups=1),
+ *   act(v) = silu?(v*gn_scale[b,c] + gn_shift[b,c]) when gn_scale != NULL (zero padding
+ *            is applied AFTER act, like the reference which pads the activated tensor).
+ * ------------------------------------------------------------------------- */
+typedef struct ddnm_conv_desc {
+    const float* src0;      /* NHWC [B][Hs][Ws][C0] */
+    const float* src1;      /* NHWC [B][Hs][Ws][C1] or NULL */
+    const float* weight;    /* packed [Cout_pad][KH*KW][Cin] (O,ky,kx,I), Cout_pad = ceil(Cout/tileN)*tileN */
+    const float* bias;      /* [Cout] or NULL */
+    const float* badd;      /* per-sample addend, row b at badd + b*badd_stride, or NULL */
+    const float* res;       /* NHWC [B][Ho][Wo][Cout] or NULL */
+    const float* gn_scale;  /* [B][Cin] or NULL */
+    const float* gn_shift;  /* [B][Cin] (required iff gn_scale) */
+    float* out;             /* NHWC [B][Ho][Wo][Cout], or NCHW [B][Cout][Ho][Wo] if out_nchw */
+    int32_t B, Hin, Win;    /* logical input size (after the optional x2 upsample) */
+    int32_t C0, C1;         /* C0 % 32 == 0, C1 % 32 == 0 (C1 = 0 without src1) */
+    int32_t Cout;
+    int32_t ksize;          /* 1 or 3 */
+    int32_t stride;         /* 1 or 2 */
+    int32_t pad;            /* top/left zero padding; bottom/right is implied by Ho, Wo */
+    int32_t Ho, Wo;
+    int32_t ups;            /* 1: src is [Hin/2][Win/2], read through nearest x2 */
+    int32_t gn_silu;        /* 1: swish after the GroupNorm affine; 0: affine only */
+    int32_t out_nchw;
+    int32_t badd_stride;
+    int32_t tile;           /* 0 auto; 1: 128x128, 2: 64x64, 3: 128x32 (M x N per workgroup) */
+} ddnm_conv_desc;
+
+int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
+/* N-tile (32 or 64 or 128) the kernel will use for this desc: Cout_pad of the packed weight. */
+int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d);
+
+/* ------------------------------------------------------------------------- *
+ * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
+ * Replaces torch.nn.GroupNorm(32, C, eps) (models.py:32-33; guided_diffusion/nn.py:17-19).
+ *   stats:    partial (sum, sumsq) per (b, chunk, group) in double, deterministic order
+ *   finalize: scale[b,c] = rstd[b,g(c)]*gamma[c]; shift[b,c] = beta[c] - mean*rstd*gamma[c]
+ * src is the concat of two NHWC tensors like the conv input (C1 = 0: single source).
+ * ------------------------------------------------------------------------- */
+int ddnm_gn_stats_f32(const float* src0, const float* src1, int32_t B, int32_t HW, int32_t C0, int32_t C1,
+                      int32_t groups, double* partial /* [B][nchunk][groups][2] */, int32_t nchunk, void* stream);
+int ddnm_gn_nchunk(int32_t HW, int32_t C);   /* chunk count `partial` must be sized for */
+int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gamma, const float* beta,
+                         int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                         float* scale /* [B][C] */, float* shift /* [B][C] */, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Batched GEMM on MFMA f32:  C = alpha * A * op(B) + beta * D
+ * A [M][K] (lda), op(B): transb=1 -> B stored [N][K] (ldb), transb=0 -> B stored [K][N];
+ * batch index i -> (i / inner, i % inner); offset = outer*stride_o + inner*stride_i per operand.
+ * Replaces torch.bmm / einsum in attention (models.py:171-185; unet.py:344-354) and the
+ * separable A / A^+ products of SRConv (functions/svd_operators.py:853-859,893-900).
+ * M, N multiples of 64; K multiple of 32.
+ * ------------------------------------------------------------------------- */
+typedef struct ddnm_gemm_desc {
+    const float* A; const float* Bm; const float* D; float* C;
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc, ldd;
+    int32_t transb;
+    int32_t batch, inner;                 /* batch = outer*inner */
+    int64_t sAo, sAi, sBo, sBi, sCo, sCi, sDo, sDi;   /* element strides */
+    float alpha, beta;
+} ddnm_gemm_desc;
+int ddnm_bgemm_f32(const ddnm_gemm_desc* d, void* stream);
+
+/* Row softmax in place: x[r][0..n) <- softmax(scale * x[r][:]); rows contiguous with ld. */
+int ddnm_softmax_rows_f32(float* x, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Small dense layers on the embedding path (models.py:216-222,306-308,92,121).
+ *   y[b][n] = bias[n] + sum_k W[n][k] * act(x[b][k]),  act = swish if silu_in else id
+ * ------------------------------------------------------------------------- */
+int ddnm_linear_f32(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t K,
+                    int32_t N, int32_t silu_in, void* stream);
+/* Sinusoidal embedding: emb[b][i] = f(t[b]*freq[i]); order 0: [sin, cos] (models.py:6-24),
+ * order 1: [cos, sin] (guided_diffusion/nn.py:103-121).  freq [half] is computed on the host. */
+int ddnm_timestep_embedding_f32(const float* t, const float* freq, float* emb, int32_t B, int32_t half,
+                                int32_t order, void* stream);
+
+/* NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad], channels >= C zero filled. */
+int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t Cpad,
+                              void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * DDNM sampler step (functions/svd_ddnm.py:57-65,74; guided_diffusion/diffusion.py:365-384).
+ * Images are NCHW fp32 [B][3][H][W].  Scalars are the host-computed alpha-bar terms:
+ *   x0   = (xt - et*sqrt(1-at)) / sqrt(at)                       (svd_ddnm.py:57)
+ *   x0h  = x0 - lambda * A^+(A x0 - y)                           (svd_ddnm.py:59-61)
+ *   xt'  = sqrt(at') * x0h + gamma*(c1*noise + c2*et)            (svd_ddnm.py:63-65)
+ * `et` may have row stride et_bstride (6-channel learn_sigma heads: first 3 used, :54-55).
+ * ------------------------------------------------------------------------- */
+typedef struct ddnm_step_scalars {
+    float sqrt_1m_at;     /* sqrt(1 - alpha_bar_t) */
+    float sqrt_at;        /* sqrt(alpha_bar_t), applied as a true division */
+    float sqrt_at_next;   /* sqrt(alpha_bar_{t'}) */
+    float c1, c2;         /* noise / eps mixing coefficients (already multiplied by gamma) */
+    float lambda;         /* 1 for DDNM (sigma_y = 0) */
+} ddnm_step_scalars;
+
+/* x0 only (first half of every step; also feeds time travel). */
+int ddnm_step_x0_f32(const float* xt, const float* et, int64_t et_bstride, float* x0, int32_t B, int64_t chw,
+                     const ddnm_step_scalars* s, void* stream);
+/* xt' = sqrt_at_next*(x0 - lambda*(proj - apy)) + c1*noise + c2*et
+ * proj = A^+ A x0 and apy = A^+ y (constant over the run), or proj = A^+(A x0 - y) with apy = NULL. */
+int ddnm_step_combine_f32(const float* x0, const float* proj, const float* apy, const float* noise,
+                          const float* et, int64_t et_bstride, float* xt_next, int32_t B, int64_t chw,
+                          const ddnm_step_scalars* s, void* stream);
+/* Fused single-pass steps (x0 written too, for time travel): */
+int ddnm_step_sr_avgpool_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
+                             const float* y /* [B][3][H/r][W/r] */, float* x0, float* xt_next, int32_t B,
+                             int32_t H, int32_t W, int32_t r, const ddnm_step_scalars* s, void* stream);
+int ddnm_step_color_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
+                        const float* y /* [B][H*W] */, float* x0, float* xt_next, int32_t B, int32_t HW,
+                        const ddnm_step_scalars* s, void* stream);
+int ddnm_step_inpaint_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
+                          const float* y /* [B][3*n_kept], HWC order of kept pixels */,
+                          const int32_t* rank /* [HW]: index of pixel among kept ones, -1 if missing */,
+                          int32_t n_kept, float* x0, float* xt_next, int32_t B, int32_t HW,
+                          const ddnm_step_scalars* s, void* stream);
+int ddnm_step_denoise_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
+                          const float* y, float* x0, float* xt_next, int32_t B, int64_t chw,
+                          const ddnm_step_scalars* s, void* stream);
+/* time-travel re-noise: xt' = a*x0 + b*noise  (svd_ddnm.py:74) */
+int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_next, int64_t n, float a, float b, void* stream);
+
+/* Stand-alone operator kernels (A and A^+ of functions/svd_operators.py, direct form). */
+int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
+int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
+int ddnm_op_color_A_f32(const float* x, float* y, int32_t B, int32_t HW, void* stream);
+int ddnm_op_color_pinv_f32(const float* y, float* x, int32_t B, int32_t HW, void* stream);
+int ddnm_op_inpaint_A_f32(const float* x, const int32_t* rank, int32_t n_kept, float* y, int32_t B, int32_t HW,
+                          void* stream);
+int ddnm_op_inpaint_pinv_f32(const float* y, const int32_t* rank, int32_t n_kept, float* x, int32_t B,
+                             int32_t HW, void* stream);
+/* Orthonormal 2-D separable Walsh-Hadamard transform H_n (x) H_n of each [n][n] plane
+ * (== the 1-D natural-order FWHT over n*n points of svd_operators.py:212-222), n in {32,...,256}.
+ * mask (optional, [planes_mask][n*n], plane p uses mask[(p % planes_mask)]) multiplies the
+ * spectrum between a forward and an inverse transform: out = H (mask .* (H in)). */
+int ddnm_fwht2d_f32(const float* in, float* out, int32_t planes, int32_t n, void* stream);
+int ddnm_fwht2d_masked_f32(const float* in, const float* mask, int32_t planes_mask, float* out,
+                           int32_t planes, int32_t n, float* scratch /* planes*n*n */, void* stream);
+/* gather/scatter between the permuted (k, c)-interleaved measurement vector and WH planes */
+int ddnm_wh_gather_f32(const float* planes, const int32_t* perm, float* y, int32_t B, int32_t C, int32_t N,
+                       int32_t n_keep, void* stream);
+int ddnm_wh_scatter_f32(const float* y, const int32_t* perm, float* planes, int32_t B, int32_t C, int32_t N,
+                        int32_t n_keep, void* stream);
+
+/* inverse_data_transform + per-image MSE (datasets/__init__.py:218-227; diffusion.py:599-602):
+ * img = clamp((x+1)/2, 0, 1); mse[b] = mean((img - clamp((x_orig+1)/2,0,1))^2) */
+int ddnm_finalize_psnr_f32(const float* x, const float* x_orig, float* img /* may be NULL */, double* sse /* [B], zeroed by callee */,
+                           int32_t B, int64_t chw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDNM_HIP_H */

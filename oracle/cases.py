@@ -1,0 +1,79 @@
+"""Seeded synthetic test cases shared by tests/golden/make_golden.py (which runs
+the REAL reference on them) and by the parity tests (which run the oracle
+restatement and the HIP engine on them).  TEST INFRASTRUCTURE.
+
+All randomness comes from CPU `torch.Generator`s (mt19937), so the same inputs
+are reproduced bit-for-bit on every box with this torch build
+(seeds fixed at 1234).
+"""
+import torch
+
+from . import operators as O
+from . import schedule, weights
+
+SEED = 1234
+
+SMALL_NET = dict(ch=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,), resolution=32)
+MID_NET = dict(ch=128, ch_mult=(1, 1, 2), num_res_blocks=2, attn_resolutions=(16,), resolution=64)
+FULL_NET = dict()   # configs/celeba_hq.yml
+
+
+def celeba_net(kind):
+    cfg = weights.celeba_config(**{"small": SMALL_NET, "mid": MID_NET, "full": FULL_NET}[kind])
+    return cfg, weights.celeba_state_dict(cfg, SEED)
+
+
+def forward_inputs(cfg, batch, seed=SEED + 1):
+    g = torch.Generator().manual_seed(seed)
+    r = cfg.data.image_size
+    x = torch.randn(batch, cfg.data.channels, r, r, generator=g)
+    t = torch.tensor([430.0, 990.0, 0.0, 10.0, 770.0, 250.0, 120.0, 640.0][:batch])
+    return x, t
+
+
+def operator_input(img_dim, batch, seed=SEED + 2):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, 3, img_dim, img_dim, generator=g)
+
+
+def random_mask(img_dim, seed=SEED + 3):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(img_dim, img_dim, generator=g) > 0.26).long()
+
+
+def wh_perm(img_dim, seed=SEED + 4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randperm(img_dim ** 2, generator=g)
+
+
+def make_operator(name, img_dim, mask=None):
+    """Oracle operator objects for the --deg names of guided_diffusion/diffusion.py:451-523."""
+    if name == "sr_averagepooling":
+        return O.SuperResolution(3, img_dim, 4)
+    if name == "sr_bicubic":
+        k = O.bicubic_kernel(4)
+        return O.SRConv(k / k.sum(), 3, img_dim, stride=4)
+    if name == "colorization":
+        return O.Colorization(img_dim)
+    if name == "inpainting":
+        mask = random_mask(img_dim) if mask is None else mask
+        return O.Inpainting(3, img_dim, O.Inpainting.missing_from_mask(mask))
+    if name == "cs_walshhadamard":
+        return O.WalshHadamardCS(3, img_dim, 4, wh_perm(img_dim))
+    if name == "denoising":
+        return O.Denoising(3, img_dim)
+    raise ValueError(name)
+
+
+def sampler_case(cfg, batch, n_iters, seed=SEED + 5):
+    """x_orig in [-1,1], x_T, and the noise tape (one tensor per loop iteration)."""
+    g = torch.Generator().manual_seed(seed)
+    r = cfg.data.image_size
+    x_orig = torch.rand(batch, 3, r, r, generator=g) * 2 - 1
+    x_T = torch.randn(batch, 3, r, r, generator=g)
+    tape = [torch.randn(batch, 3, r, r, generator=g) for _ in range(n_iters)]
+    return x_orig, x_T, tape
+
+
+def betas():
+    return schedule.beta_schedule("linear", 1e-4, 0.02, 1000)

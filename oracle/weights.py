@@ -1,0 +1,150 @@
+"""Deterministic seeded state-dicts with the reference's key names
+(TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+No pretrained checkpoints exist offline, so parity
+runs on seeded random weights.  The key lists restate the constructors
+  * guided_diffusion/models.py:192-299   (celeba `Model`)
+  * guided_diffusion/unet.py:396-633     (ImageNet `UNetModel`, built by
+                                          script_util.py:130-185)
+and are pinned against the real constructors' `state_dict()` in
+tests/test_oracle_pins.py (golden key/shape lists in tests/golden/).
+
+Every tensor -- including those the reference zero-initialises with
+`zero_module` (nn.py:68) -- gets non-trivial values, otherwise the ADM UNet
+outputs exactly 0 and parity is vacuous.
+"""
+import types
+from collections import OrderedDict
+
+import torch
+
+
+def celeba_config(ch=128, ch_mult=(1, 1, 2, 2, 4, 4), num_res_blocks=2, attn_resolutions=(16,),
+                  resolution=256, in_channels=3, out_ch=3):
+    """Namespace shaped like the YAML config (configs/celeba_hq.yml:14-40)."""
+    model = types.SimpleNamespace(type="simple", in_channels=in_channels, out_ch=out_ch, ch=ch,
+                                  ch_mult=list(ch_mult), num_res_blocks=num_res_blocks,
+                                  attn_resolutions=list(attn_resolutions), dropout=0.0,
+                                  var_type="fixedsmall", ema_rate=0.999, ema=True,
+                                  resamp_with_conv=True)
+    data = types.SimpleNamespace(dataset="CelebA_HQ", image_size=resolution, channels=in_channels,
+                                 logit_transform=False, uniform_dequantization=False,
+                                 gaussian_dequantization=False, random_flip=True, rescaled=True,
+                                 num_workers=0, out_of_dist=False, category="")
+    diffusion = types.SimpleNamespace(beta_schedule="linear", beta_start=1e-4, beta_end=0.02,
+                                      num_diffusion_timesteps=1000)
+    sampling = types.SimpleNamespace(batch_size=1)
+    tt = types.SimpleNamespace(T_sampling=100, travel_length=1, travel_repeat=1)
+    return types.SimpleNamespace(model=model, data=data, diffusion=diffusion, sampling=sampling,
+                                 time_travel=tt)
+
+
+def _conv(shapes, name, cout, cin, k):
+    shapes[name + ".weight"] = (cout, cin, k, k)
+    shapes[name + ".bias"] = (cout,)
+
+
+def _lin(shapes, name, cout, cin):
+    shapes[name + ".weight"] = (cout, cin)
+    shapes[name + ".bias"] = (cout,)
+
+
+def _gn(shapes, name, c):
+    shapes[name + ".weight"] = (c,)
+    shapes[name + ".bias"] = (c,)
+
+
+def _resblock(shapes, name, cin, cout, temb_ch):
+    _gn(shapes, name + ".norm1", cin)
+    _conv(shapes, name + ".conv1", cout, cin, 3)
+    _lin(shapes, name + ".temb_proj", cout, temb_ch)
+    _gn(shapes, name + ".norm2", cout)
+    _conv(shapes, name + ".conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(shapes, name + ".nin_shortcut", cout, cin, 1)
+
+
+def _attn(shapes, name, c):
+    _gn(shapes, name + ".norm", c)
+    for p in ("q", "k", "v", "proj_out"):
+        _conv(shapes, f"{name}.{p}", c, c, 1)
+
+
+def celeba_shapes(config):
+    """(name -> shape) in the registration order of models.py::Model.__init__."""
+    m = config.model
+    ch, mult, nrb = m.ch, tuple(m.ch_mult), m.num_res_blocks
+    temb_ch = 4 * ch
+    nres = len(mult)
+    in_mult = (1,) + mult
+    s = OrderedDict()
+    _lin(s, "temb.dense.0", temb_ch, ch)
+    _lin(s, "temb.dense.1", temb_ch, temb_ch)
+    _conv(s, "conv_in", ch, m.in_channels, 3)
+    res = config.data.image_size
+    block_in = None
+    for lvl in range(nres):
+        block_in = ch * in_mult[lvl]
+        block_out = ch * mult[lvl]
+        names_attn = []
+        for ib in range(nrb):
+            _resblock(s, f"down.{lvl}.block.{ib}", block_in, block_out, temb_ch)
+            block_in = block_out
+            if res in m.attn_resolutions:
+                names_attn.append(f"down.{lvl}.attn.{len(names_attn)}")
+        # nn.Module registers `block` before `attn`: all blocks first, then attns
+        for n in names_attn:
+            _attn(s, n, block_in)
+        if lvl != nres - 1:
+            _conv(s, f"down.{lvl}.downsample.conv", block_in, block_in, 3)
+            res //= 2
+    _resblock(s, "mid.block_1", block_in, block_in, temb_ch)
+    _attn(s, "mid.attn_1", block_in)
+    _resblock(s, "mid.block_2", block_in, block_in, temb_ch)
+    ups = {}
+    for lvl in reversed(range(nres)):
+        u = OrderedDict()
+        block_out = ch * mult[lvl]
+        skip_in = ch * mult[lvl]
+        n_attn = 0
+        for ib in range(nrb + 1):
+            if ib == nrb:
+                skip_in = ch * in_mult[lvl]
+            _resblock(u, f"up.{lvl}.block.{ib}", block_in + skip_in, block_out, temb_ch)
+            block_in = block_out
+            if res in m.attn_resolutions:
+                n_attn += 1
+        for ia in range(n_attn):
+            _attn(u, f"up.{lvl}.attn.{ia}", block_in)
+        if lvl != 0:
+            _conv(u, f"up.{lvl}.upsample.conv", block_in, block_in, 3)
+            res *= 2
+        ups[lvl] = u
+    for lvl in range(nres):          # `self.up.insert(0, up)` -> stored by level index
+        s.update(ups[lvl])
+    _gn(s, "norm_out", block_in)
+    _conv(s, "conv_out", m.out_ch, block_in, 3)
+    return s
+
+
+def fill(shapes, seed):
+    """Seeded fp32 tensors: weights ~ N(0, 1/fan_in), GN affine ~ (1 + 0.1 N, 0.1 N),
+    all biases (conv, linear, GN beta) ~ 0.05 N.  CPU mt19937 => identical on every box with this torch build."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+        elif name.endswith(".weight"):            # GroupNorm gamma
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        else:
+            t = 0.05 * torch.randn(shape, generator=g)
+        sd[name] = t.float().contiguous()
+    return sd
+
+
+def celeba_state_dict(config, seed=1234):
+    return fill(celeba_shapes(config), seed)

@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference, CPU) on the seeded cases of oracle/cases.py.
+
+Run once in the build container:   python tests/golden/make_golden.py [--full]
+The reference ships no golden vectors of its own, so these
+files are what pins the oracle restatement -- and, through it, the HIP engine --
+to the reference's behaviour.  `--full` additionally runs the 100-step
+celeba_hq / sr_bicubic 4x case (BASELINE config 2 at B=1, about 2-3 min of CPU).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import cases, ref_import, schedule  # noqa: E402
+
+OPS = ["sr_averagepooling", "sr_bicubic", "colorization", "inpainting", "cs_walshhadamard", "denoising"]
+
+
+def ref_operator(R, name, d, mask=None):
+    from oracle import operators as O
+    if name == "sr_averagepooling":
+        return R.SuperResolution(3, d, 4, "cpu")
+    if name == "sr_bicubic":
+        k = O.bicubic_kernel(4)            # restates diffusion.py:485-499 (checked below)
+        return R.SRConv(k / k.sum(), 3, d, "cpu", stride=4)
+    if name == "colorization":
+        return R.Colorization(d, "cpu")
+    if name == "inpainting":
+        mask = cases.random_mask(d) if mask is None else mask
+        m = mask.reshape(-1)
+        r = torch.nonzero(m == 0).long().reshape(-1) * 3          # diffusion.py:465-470
+        op = R.Inpainting.__new__(R.Inpainting)                    # skip the O(n*m) python loop (:330)
+        op.channels, op.img_dim = 3, d
+        missing = torch.cat([r, r + 1, r + 2], dim=0)
+        op._singulars = torch.ones(3 * d * d - missing.shape[0])
+        op.missing_indices = missing
+        keep = torch.ones(3 * d * d, dtype=torch.bool)
+        keep[missing] = False
+        op.kept_indices = torch.nonzero(keep).reshape(-1).long()   # == the list comprehension of :330
+        return op
+    if name == "cs_walshhadamard":
+        return R.WalshHadamardCS(3, d, 4, cases.wh_perm(d), "cpu")
+    if name == "denoising":
+        return R.Denoising(3, d, "cpu")
+    raise ValueError(name)
+
+
+def sub(t, step=8):
+    return t[..., ::step, ::step].contiguous().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    ns = ref_import.load()
+    R = ns.svd_operators
+    torch.set_num_threads(os.cpu_count())
+
+    # 1. state-dict key/shape list of the real constructor (full celeba config)
+    cfg_full, sd_full = cases.celeba_net("full")
+    ref_full = ns.models.Model(cfg_full)
+    keys = [[k, list(v.shape)] for k, v in ref_full.state_dict().items()]
+    json.dump(keys, open(os.path.join(HERE, "celeba_state_dict_keys.json"), "w"))
+
+    # 2. schedules
+    sched = {f"jump_{T}_{l}_{r}": np.array(ns.svd_ddnm.get_schedule_jump(T, l, r))
+             for (T, l, r) in [(100, 1, 1), (100, 10, 3), (100, 2, 2), (20, 2, 2)]}
+    b = cases.betas()
+    ab = ns.svd_ddnm.compute_alpha(b, torch.arange(-1, 1000)).reshape(-1)
+    sched["alpha_bar_m1_to_999"] = ab.numpy()
+    np.savez_compressed(os.path.join(HERE, "schedule.npz"), **sched)
+
+    # 3. operators
+    out = {}
+    mask_real = torch.from_numpy(np.load(os.path.join(ref_import.REF_ROOT, "exp/inp_masks/mask.npy")))
+    np.savez_compressed(os.path.join(HERE, "inp_mask.npz"), packed=np.packbits(mask_real.numpy().astype(np.uint8)),
+                        shape=np.array(mask_real.shape))
+    for d in (64, 256):
+        x = cases.operator_input(d, 2)
+        for name in OPS:
+            mask = mask_real if (name == "inpainting" and d == 256) else None
+            op = ref_operator(R, name, d, mask)
+            y = op.A(x)
+            p = op.A_pinv(y.clone())
+            out[f"{name}_{d}_y"] = y.numpy() if d == 64 else y[:, ::31].contiguous().numpy()
+            out[f"{name}_{d}_pinv"] = (p.reshape(2, 3, d, d).numpy() if d == 64
+                                       else sub(p.reshape(2, 3, d, d), 8))
+            out[f"{name}_{d}_ysum"] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+    # bicubic kernel as built by the reference runner (diffusion.py:485-499), re-executed verbatim
+    # through the oracle's restatement and compared against the SRConv it feeds
+    np.savez_compressed(os.path.join(HERE, "operators.npz"), **out)
+
+    # 4. UNet forwards
+    fw = {}
+    for kind, batch in (("small", 2), ("mid", 2), ("full", 1)):
+        cfg, sd = cases.celeba_net(kind)
+        ref = ns.models.Model(cfg)
+        ref.load_state_dict(sd)
+        ref.eval()
+        x, t = cases.forward_inputs(cfg, batch)
+        with torch.no_grad():
+            e = ref(x, t)
+        fw[f"{kind}_eps"] = e.numpy() if kind != "full" else sub(e, 4)
+        fw[f"{kind}_stats"] = np.array([e.double().mean().item(), e.double().std().item(),
+                                        e.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(HERE, "celeba_forward.npz"), **fw)
+
+    # 5. sampler, small net, every operator, with time travel
+    sm = {}
+    cfg, sd = cases.celeba_net("small")
+    ref = ns.models.Model(cfg)
+    ref.load_state_dict(sd)
+    ref.eval()
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 20, 2, 2
+    n_it = len(schedule.jump_times(20, 2, 2)) - 1
+    d = cfg.data.image_size
+    for name in OPS:
+        x_orig, x_T, tape = cases.sampler_case(cfg, 2, n_it)
+        op = ref_operator(R, name, d)
+        y = op.A(x_orig)
+        with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+            xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, b, 0.85, op, y, cls_fn=None,
+                                                 classes=None, config=cfg)
+        sm[f"{name}_x"] = xs[0].numpy()
+        sm[f"{name}_x0"] = x0s[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "ddnm_small.npz"), **sm)
+
+    # 6. BASELINE config 2 at B=1: celeba_hq Model, sr_bicubic 4x, T=100 (slow)
+    if args.full:
+        import time
+        cfg, sd = cases.celeba_net("full")
+        ref = ns.models.Model(cfg)
+        ref.load_state_dict(sd)
+        ref.eval()
+        x_orig, x_T, tape = cases.sampler_case(cfg, 1, 100)
+        op = ref_operator(R, "sr_bicubic", 256)
+        y = op.A(x_orig)
+        t0 = time.perf_counter()
+        with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+            xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, b, 0.85, op, y, cls_fn=None,
+                                                 classes=None, config=cfg)
+        dt = time.perf_counter() - t0
+        x = xs[0]
+        from oracle import sampler
+        np.savez_compressed(os.path.join(HERE, "ddnm_full_c2.npz"), x_sub=sub(x, 4), x0_sub=sub(x0s[0], 4),
+                            psnr=sampler.psnr(x, x_orig).numpy(),
+                            stats=np.array([x.double().mean().item(), x.double().std().item()]),
+                            ref_cpu_seconds=np.array([dt]), ref_cpu_threads=np.array([torch.get_num_threads()]))
+        print("full c2: %.1f s, psnr %s" % (dt, sampler.psnr(x, x_orig)))
+
+
+if __name__ == "__main__":
+    main()
