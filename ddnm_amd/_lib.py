@@ -1,0 +1,118 @@
+"""ctypes binding of libddnm_hip.so (the C ABI declared in include/ddnm_hip.h).
+
+The product path has NO CPU / PyTorch fallback: if the shared library is missing
+or a kernel returns an error, this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libddnm_hip.so")
+
+c_f32p = c_void_p   # device pointers travel as raw addresses
+
+
+class ConvDesc(Structure):
+    _fields_ = [
+        ("src0", c_void_p), ("src1", c_void_p), ("weight", c_void_p), ("bias", c_void_p),
+        ("badd", c_void_p), ("res", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p),
+        ("out", c_void_p),
+        ("B", c_int32), ("Hin", c_int32), ("Win", c_int32),
+        ("C0", c_int32), ("C1", c_int32), ("Cout", c_int32),
+        ("ksize", c_int32), ("stride", c_int32), ("pad", c_int32),
+        ("Ho", c_int32), ("Wo", c_int32),
+        ("ups", c_int32), ("gn_silu", c_int32), ("out_nchw", c_int32),
+        ("badd_stride", c_int32), ("tile", c_int32),
+    ]
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("Bm", c_void_p), ("D", c_void_p), ("C", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldb", c_int32), ("ldc", c_int32), ("ldd", c_int32),
+        ("transb", c_int32), ("batch", c_int32), ("inner", c_int32),
+        ("sAo", c_int64), ("sAi", c_int64), ("sBo", c_int64), ("sBi", c_int64),
+        ("sCo", c_int64), ("sCi", c_int64), ("sDo", c_int64), ("sDi", c_int64),
+        ("alpha", c_float), ("beta", c_float),
+    ]
+
+
+class StepScalars(Structure):
+    _fields_ = [("sqrt_1m_at", c_float), ("sqrt_at", c_float), ("sqrt_at_next", c_float),
+                ("c1", c_float), ("c2", c_float), ("lam", c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/ddnm_hip.h declares
+PROTOTYPES = {
+    "ddnm_version": (c_int32, []),
+    "ddnm_error_string": (c_char_p, [c_int32]),
+    "ddnm_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_gn_stats_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                    c_int32, c_void_p]),
+    "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),
+    "ddnm_gn_finalize_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                       c_float, c_void_p, c_void_p, c_void_p]),
+    "ddnm_bgemm_f32": (c_int32, [POINTER(GemmDesc), c_void_p]),
+    "ddnm_softmax_rows_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "ddnm_linear_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                  c_void_p]),
+    "ddnm_timestep_embedding_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_nchw_to_nhwc_pad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_step_x0_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, POINTER(StepScalars),
+                                   c_void_p]),
+    "ddnm_step_combine_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                        c_int32, c_int64, POINTER(StepScalars), c_void_p]),
+    "ddnm_step_sr_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int32, c_int32, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
+    "ddnm_step_color_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int32, c_int32, POINTER(StepScalars), c_void_p]),
+    "ddnm_step_inpaint_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
+                                        c_void_p, c_void_p, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
+    "ddnm_step_denoise_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int32, c_int64, POINTER(StepScalars), c_void_p]),
+    "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_op_upsample_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_op_color_A_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_op_color_pinv_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_op_inpaint_A_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_op_inpaint_pinv_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_fwht2d_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_fwht2d_masked_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p,
+                                         c_void_p]),
+    "ddnm_wh_gather_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_wh_scatter_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_finalize_psnr_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class DDNMHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DDNMHipError(
+                f"{LIB_PATH} is missing: build it with `python -m ddnm_amd.build` "
+                "(the DDNM hot path has no CPU/PyTorch fallback)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().ddnm_error_string(code)
+        raise DDNMHipError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")

@@ -102,12 +102,44 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(const ddnm_gemm_desc d, 
         }
 }
 
+
+// Fallback for shapes the MFMA tiling does not cover (tiny test sizes): one thread per output.
+__global__ __launch_bounds__(256) void bgemm_naive_kernel(const ddnm_gemm_desc d) {
+    const int64_t per = (int64_t)d.M * d.N;
+    const int64_t total = per * d.batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bi = i / per, r = i - bi * per;
+        const int m = (int)(r / d.N), n = (int)(r - (int64_t)m * d.N);
+        const int64_t bo = bi / d.inner, bn = bi - bo * d.inner;
+        const float* A = d.A + bo * d.sAo + bn * d.sAi + (size_t)m * d.lda;
+        const float* Bm = d.Bm + bo * d.sBo + bn * d.sBi;
+        float acc = 0.f;
+        if (d.transb) {
+            const float* Br = Bm + (size_t)n * d.ldb;
+            for (int k = 0; k < d.K; ++k) acc += A[k] * Br[k];
+        } else {
+            for (int k = 0; k < d.K; ++k) acc += A[k] * Bm[(size_t)k * d.ldb + n];
+        }
+        float v = d.alpha * acc;
+        if (d.D) v += d.beta * d.D[bo * d.sDo + bn * d.sDi + (size_t)m * d.ldd + n];
+        d.C[bo * d.sCo + bn * d.sCi + (size_t)m * d.ldc + n] = v;
+    }
+}
+
 extern "C" int ddnm_bgemm_f32(const ddnm_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->Bm || !d->C) return DDNM_E_BADARG;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch <= 0 || d->inner <= 0) return DDNM_E_BADARG;
-    if (d->M % 64 || d->N % 64 || d->K % KC || d->batch % d->inner) return DDNM_E_SHAPE;
-    if ((d->lda | d->ldb) & 3) return DDNM_E_SHAPE;   // float4 loads
+    if (d->batch % d->inner) return DDNM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    const bool aligned = ((d->lda | d->ldb) & 3) == 0 && ((d->sAo | d->sAi | d->sBo | d->sBi) & 3) == 0 &&
+                         (((uintptr_t)d->A | (uintptr_t)d->Bm) & 15) == 0;
+    if (d->M % 64 || d->N % 64 || d->K % KC || !aligned) {
+        const int64_t total = (int64_t)d->M * d->N * d->batch;
+        const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(bgemm_naive_kernel, dim3(grid), dim3(256), 0, s, *d);
+        DDNM_LAUNCH_CHECK();
+        return 0;
+    }
     const bool big = (d->M % 128 == 0) && (d->N % 128 == 0) &&
                      ((long)d->batch * (d->M / 128) * (d->N / 128) >= 256);
     if (big) {

@@ -1,0 +1,369 @@
+"""Degradation operators of DDNM on MI355X, behind the reference's `A_functions` API.
+
+Drop-in for `functions/svd_operators.py` on the hot path: the classes keep the
+reference's names and constructor signatures and expose `A(vec)`, `A_pinv(vec)`
+(`[B, ...] -> [B, D]` contiguous fp32) plus `singulars()`.  The reference applies
+each operator through its SVD factors (U, Sigma, V^T; svd_operators.py:52-80) with
+~60 tiny ATen launches per call; here each A / A^+ is the operator's direct form
+as one (or a few) hand-written HIP kernels:
+
+  SuperResolution  -> r x r mean / replicate                    (svd_operators.py:479-533)
+  SRConv           -> Ae X Ae^T / Pe Y Pe^T on MFMA f32          (svd_operators.py:851-931)
+  Colorization     -> w . rgb / w |w|^-2                         (svd_operators.py:627-667)
+  Inpainting       -> gather / scatter through a rank table      (svd_operators.py:324-359)
+  WalshHadamardCS  -> separable FWHT (shuffle + LDS) + permuted mask (svd_operators.py:211-251)
+  Denoising        -> identity                                   (svd_operators.py:442-462)
+
+Every class also implements `ddnm_step(...)`, the fused x0 / projection / DDIM
+update of one sampler step (functions/svd_ddnm.py:57-65) that `ddnm_diffusion`
+uses when it is handed one of these objects.
+
+`Lambda` / `Lambda_noise` (the sigma_y > 0 path) are
+not built yet and raise NotImplementedError like the reference does for SRConv.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _img(vec, c, d):
+    v = vec.reshape(vec.shape[0], c, d, d)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    return v
+
+
+class A_functions:
+    """Abstract base, same surface as svd_operators.py:9-97 (matrix-free SVD operator)."""
+
+    channels = 3
+    img_dim = 256
+
+    def A(self, vec):
+        raise NotImplementedError()
+
+    def A_pinv(self, vec):
+        raise NotImplementedError()
+
+    def singulars(self):
+        raise NotImplementedError()
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):
+        raise NotImplementedError()
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):
+        raise NotImplementedError()
+
+    # ---- engine hook -----------------------------------------------------------------
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        """Generic step: x0, proj = A^+(A x0 - y), combine.  Subclasses fuse it."""
+        B = xt.shape[0]
+        ops.step_x0(xt, et, s, out=x0_out)
+        resid = self.A(x0_out) - y.reshape(B, -1)          # tiny elementwise; overridden where it matters
+        proj = self.A_pinv(resid).reshape(xt.shape)
+        ops.step_combine(x0_out, proj, None, noise, et, s, out=xt_next)
+
+
+class Denoising(A_functions):
+    def __init__(self, channels, img_dim, device):
+        self.channels, self.img_dim, self.device = channels, img_dim, device
+
+    def A(self, vec):
+        return vec.reshape(vec.shape[0], -1).clone()
+
+    def A_pinv(self, vec):
+        return vec.reshape(vec.shape[0], -1).clone()
+
+    def singulars(self):
+        return torch.ones(self.channels * self.img_dim ** 2, device=self.device)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        B = xt.shape[0]
+        ep, es = ops._et_args(et)
+        check(_lib.lib().ddnm_step_denoise_f32(_p(xt), ep, es, _p(noise), _p(y), _p(x0_out), _p(xt_next), B,
+                                               xt.numel() // B, ctypes.byref(s), ops._stream()),
+              "ddnm_step_denoise_f32")
+
+
+class SuperResolution(A_functions):
+    def __init__(self, channels, img_dim, ratio, device):
+        assert img_dim % ratio == 0
+        self.channels, self.img_dim, self.ratio, self.device = channels, img_dim, ratio, device
+        self.y_dim = img_dim // ratio
+
+    def A(self, vec):
+        x = _img(vec, self.channels, self.img_dim)
+        B = x.shape[0]
+        y = torch.empty(B, self.channels * self.y_dim ** 2, dtype=torch.float32, device=x.device)
+        check(_lib.lib().ddnm_op_avgpool_f32(_p(x), _p(y), B * self.channels, self.img_dim, self.img_dim, self.ratio,
+                                             ops._stream()), "ddnm_op_avgpool_f32")
+        return y
+
+    def A_pinv(self, vec):
+        B = vec.shape[0]
+        y = vec.reshape(B, -1).float().contiguous()
+        x = torch.empty(B, self.channels * self.img_dim ** 2, dtype=torch.float32, device=y.device)
+        check(_lib.lib().ddnm_op_upsample_f32(_p(y), _p(x), B * self.channels, self.img_dim, self.img_dim, self.ratio,
+                                              ops._stream()), "ddnm_op_upsample_f32")
+        return x
+
+    def singulars(self):
+        return torch.full((self.channels * self.y_dim ** 2,), 1.0 / self.ratio, device=self.device)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        if self.ratio != 4 or self.channels != 3:
+            return super().ddnm_step(xt, et, noise, y, s, x0_out, xt_next)
+        B = xt.shape[0]
+        ep, es = ops._et_args(et)
+        check(_lib.lib().ddnm_step_sr_avgpool_f32(_p(xt), ep, es, _p(noise), _p(y), _p(x0_out), _p(xt_next), B,
+                                                  self.img_dim, self.img_dim, self.ratio, ctypes.byref(s),
+                                                  ops._stream()), "ddnm_step_sr_avgpool_f32")
+
+
+class Colorization(A_functions):
+    def __init__(self, img_dim, device):
+        self.channels, self.img_dim, self.device = 3, img_dim, device
+
+    def A(self, vec):
+        x = _img(vec, 3, self.img_dim)
+        B, HW = x.shape[0], self.img_dim ** 2
+        y = torch.empty(B, HW, dtype=torch.float32, device=x.device)
+        check(_lib.lib().ddnm_op_color_A_f32(_p(x), _p(y), B, HW, ops._stream()), "ddnm_op_color_A_f32")
+        return y
+
+    def A_pinv(self, vec):
+        B, HW = vec.shape[0], self.img_dim ** 2
+        y = vec.reshape(B, -1).float().contiguous()
+        x = torch.empty(B, 3 * HW, dtype=torch.float32, device=y.device)
+        check(_lib.lib().ddnm_op_color_pinv_f32(_p(y), _p(x), B, HW, ops._stream()), "ddnm_op_color_pinv_f32")
+        return x
+
+    def singulars(self):
+        w = torch.tensor([0.3333, 0.3334, 0.3333])
+        return torch.full((self.img_dim ** 2,), float((w * w).sum().sqrt()), device=self.device)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        B = xt.shape[0]
+        ep, es = ops._et_args(et)
+        check(_lib.lib().ddnm_step_color_f32(_p(xt), ep, es, _p(noise), _p(y), _p(x0_out), _p(xt_next), B,
+                                             self.img_dim ** 2, ctypes.byref(s), ops._stream()), "ddnm_step_color_f32")
+
+
+class Inpainting(A_functions):
+    def __init__(self, channels, img_dim, missing_indices, device):
+        if channels != 3:
+            raise NotImplementedError("Inpainting kernels assume 3 channels")
+        self.channels, self.img_dim, self.device = channels, img_dim, device
+        hw = img_dim ** 2
+        # `missing_indices` index the HWC-interleaved image (guided_diffusion/diffusion.py:465-470);
+        # a pixel is missing iff its 3 interleaved entries are.
+        miss = torch.zeros(3 * hw, dtype=torch.bool)
+        miss[missing_indices.detach().cpu().long()] = True
+        miss = miss.reshape(hw, 3)
+        if not bool((miss.all(1) == miss.any(1)).all()):
+            raise NotImplementedError("per-channel masks are not supported (reference masks whole pixels)")
+        keep = ~miss[:, 0]
+        rank = torch.cumsum(keep.int(), 0) - 1
+        rank[~keep] = -1
+        self.n_kept = int(keep.sum())
+        self.rank = rank.to(torch.int32).to(device).contiguous()
+        self.missing_indices = missing_indices
+
+    def A(self, vec):
+        x = _img(vec, 3, self.img_dim)
+        B = x.shape[0]
+        y = torch.empty(B, 3 * self.n_kept, dtype=torch.float32, device=x.device)
+        check(_lib.lib().ddnm_op_inpaint_A_f32(_p(x), _p(self.rank), self.n_kept, _p(y), B, self.img_dim ** 2,
+                                               ops._stream()), "ddnm_op_inpaint_A_f32")
+        return y
+
+    def A_pinv(self, vec):
+        B = vec.shape[0]
+        y = vec.reshape(B, -1).float().contiguous()
+        x = torch.empty(B, 3 * self.img_dim ** 2, dtype=torch.float32, device=y.device)
+        check(_lib.lib().ddnm_op_inpaint_pinv_f32(_p(y), _p(self.rank), self.n_kept, _p(x), B, self.img_dim ** 2,
+                                                  ops._stream()), "ddnm_op_inpaint_pinv_f32")
+        return x
+
+    def singulars(self):
+        return torch.ones(3 * self.n_kept, device=self.device)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        B = xt.shape[0]
+        ep, es = ops._et_args(et)
+        check(_lib.lib().ddnm_step_inpaint_f32(_p(xt), ep, es, _p(noise), _p(y), _p(self.rank), self.n_kept,
+                                               _p(x0_out), _p(xt_next), B, self.img_dim ** 2, ctypes.byref(s),
+                                               ops._stream()), "ddnm_step_inpaint_f32")
+
+
+class WalshHadamardCS(A_functions):
+    def __init__(self, channels, img_dim, ratio, perm, device):
+        self.channels, self.img_dim, self.ratio, self.device = channels, img_dim, ratio, device
+        self.N = img_dim ** 2
+        self.n_keep = channels * self.N // ratio
+        self.perm = perm.to(device=device, dtype=torch.int32).contiguous()
+        # spectral mask W[c][q] = 1 iff the (k, c)-interleaved index of q = perm[k] is measured
+        k = torch.arange(self.N)
+        mask = torch.zeros(channels, self.N)
+        pc = perm.detach().cpu().long()
+        for c in range(channels):
+            mask[c, pc] = ((k * channels + c) < self.n_keep).float()
+        self.mask = mask.to(device).contiguous()
+        self._scratch = None
+        self._apy = None
+        self._apy_key = None
+
+    def _buf(self, B):
+        if self._scratch is None or self._scratch.shape[0] < B:
+            self._scratch = torch.empty(B, self.channels, self.N, dtype=torch.float32, device=self.device)
+        return self._scratch
+
+    def A(self, vec):
+        x = _img(vec, self.channels, self.img_dim)
+        B = x.shape[0]
+        coef = torch.empty_like(x)
+        L = _lib.lib()
+        check(L.ddnm_fwht2d_f32(_p(x), _p(coef), B * self.channels, self.img_dim, ops._stream()), "ddnm_fwht2d_f32")
+        y = torch.empty(B, self.n_keep, dtype=torch.float32, device=x.device)
+        check(L.ddnm_wh_gather_f32(_p(coef), _p(self.perm), _p(y), B, self.channels, self.N, self.n_keep,
+                                   ops._stream()), "ddnm_wh_gather_f32")
+        return y
+
+    def A_pinv(self, vec):
+        B = vec.shape[0]
+        y = vec.reshape(B, -1).float().contiguous()
+        planes = torch.empty(B, self.channels, self.N, dtype=torch.float32, device=y.device)
+        L = _lib.lib()
+        check(L.ddnm_wh_scatter_f32(_p(y), _p(self.perm), _p(planes), B, self.channels, self.N, self.n_keep,
+                                    ops._stream()), "ddnm_wh_scatter_f32")
+        out = torch.empty_like(planes)
+        check(L.ddnm_fwht2d_f32(_p(planes), _p(out), B * self.channels, self.img_dim, ops._stream()),
+              "ddnm_fwht2d_f32")
+        return out.reshape(B, -1)
+
+    def singulars(self):
+        return torch.ones(self.n_keep, device=self.device)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        # A^+(A x0 - y) = H(W .* H x0) - A^+ y ; A^+ y is constant over the run
+        B = xt.shape[0]
+        key = (y.data_ptr(), y._version, B)
+        if self._apy_key != key:
+            self._apy = self.A_pinv(y).reshape(xt.shape)
+            self._apy_key = key
+        ops.step_x0(xt, et, s, out=x0_out)
+        proj = torch.empty_like(xt)
+        check(_lib.lib().ddnm_fwht2d_masked_f32(_p(x0_out), _p(self.mask), self.channels, _p(proj),
+                                                B * self.channels, self.img_dim, _p(self._buf(B)), ops._stream()),
+              "ddnm_fwht2d_masked_f32")
+        ops.step_combine(x0_out, proj, self._apy, noise, et, s, out=xt_next)
+
+
+class SRConv(A_functions):
+    ZERO = 3e-2     # svd_operators.py:878
+
+    def __init__(self, kernel, channels, img_dim, device, stride=1):
+        self.channels, self.img_dim, self.ratio, self.device = channels, img_dim, stride, device
+        self.small_dim = small = img_dim // stride
+        # 1-D strided blur matrix with reflective padding (svd_operators.py:862-875); host-side setup
+        k = kernel.detach().float().cpu()
+        A_small = torch.zeros(small, img_dim)
+        half = k.shape[0] // 2
+        for i in range(stride // 2, img_dim + stride // 2, stride):
+            for j in range(i - half, i + half):
+                je = j
+                if je < 0:
+                    je = -je - 1
+                if je >= img_dim:
+                    je = (img_dim - 1) - (je - img_dim)
+                A_small[i // stride, je] += k[j - i + half]
+        U, S, V = torch.svd(A_small, some=False)
+        S = S.clone()
+        S[S < self.ZERO] = 0
+        Sp = torch.where(S > 0, 1.0 / S, torch.zeros_like(S))
+        self.singulars_small = S.to(device)
+        self.Ae = ((U * S[None, :]) @ V[:, :small].T).contiguous().to(device)       # [small, img_dim]
+        self.Pe = ((V[:, :small] * Sp[None, :]) @ U.T).contiguous().to(device)      # [img_dim, small]
+
+    def _A(self, x, y_sub=None):
+        """Y = Ae X Ae^T (- y_sub) for every (b, c) plane."""
+        B = x.shape[0]
+        bc, d, m = B * self.channels, self.img_dim, self.small_dim
+        t1 = torch.empty(bc, m, d, dtype=torch.float32, device=x.device)
+        ops.bgemm(self.Ae, x, t1, m, d, d, lda=d, ldb=d, ldc=d, transb=False, batch=bc, sB=(d * d, 0), sC=(m * d, 0))
+        y = torch.empty(B, self.channels * m * m, dtype=torch.float32, device=x.device)
+        ops.bgemm(t1, self.Ae, y, m, m, d, lda=d, ldb=d, ldc=m, transb=True, batch=bc, sA=(m * d, 0), sC=(m * m, 0),
+                  D=y_sub, ldd=m, sD=(m * m, 0), beta=-1.0)
+        return y
+
+    def A(self, vec):
+        return self._A(_img(vec, self.channels, self.img_dim))
+
+    def A_pinv(self, vec):
+        B = vec.shape[0]
+        y = vec.reshape(B, -1).float().contiguous()
+        bc, d, m = B * self.channels, self.img_dim, self.small_dim
+        t2 = torch.empty(bc, d, m, dtype=torch.float32, device=y.device)
+        ops.bgemm(self.Pe, y, t2, d, m, m, lda=m, ldb=m, ldc=m, transb=False, batch=bc, sB=(m * m, 0), sC=(d * m, 0))
+        x = torch.empty(B, self.channels * d * d, dtype=torch.float32, device=y.device)
+        ops.bgemm(t2, self.Pe, x, d, d, m, lda=m, ldb=m, ldc=d, transb=True, batch=bc, sA=(d * m, 0), sC=(d * d, 0))
+        return x
+
+    def singulars(self):
+        s = self.singulars_small
+        return torch.matmul(s.reshape(-1, 1), s.reshape(1, -1)).reshape(-1).repeat_interleave(3).reshape(-1)
+
+    def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
+        B = xt.shape[0]
+        ops.step_x0(xt, et, s, out=x0_out)
+        resid = self._A(x0_out, y_sub=y.reshape(B, -1))          # A x0 - y fused in the GEMM epilogue
+        proj = self.A_pinv(resid).reshape(xt.shape)
+        ops.step_combine(x0_out, proj, None, noise, et, s, out=xt_next)
+
+
+def build_operator(deg, deg_scale, config, device, mask_path="exp/inp_masks/mask.npy", perm=None):
+    """Operator factory of guided_diffusion/diffusion.py:451-523 for the --deg values on the hot path."""
+    c, d = config.data.channels, config.data.image_size
+    if deg == "cs_walshhadamard":
+        compress_by = round(1 / deg_scale)
+        if perm is None:
+            perm = torch.randperm(d ** 2, device=device)     # global device RNG, diffusion.py:458
+        return WalshHadamardCS(c, d, compress_by, perm, device)
+    if deg == "inpainting":
+        mask = torch.from_numpy(np.load(mask_path)).reshape(-1)
+        r = torch.nonzero(mask == 0).long().reshape(-1) * 3
+        return Inpainting(c, d, torch.cat([r, r + 1, r + 2], dim=0), device)
+    if deg == "denoising":
+        return Denoising(c, d, device)
+    if deg == "colorization":
+        return Colorization(d, device)
+    if deg == "sr_averagepooling":
+        return SuperResolution(c, d, int(deg_scale), device)
+    if deg == "sr_bicubic":
+        factor = int(deg_scale)
+        return SRConv(bicubic_kernel(factor), c, d, device, stride=factor)
+    raise ValueError("degradation type not supported")
+
+
+def bicubic_kernel(factor):
+    """diffusion.py:485-499: cubic (a=-0.5) taps, normalised in float64 then again in fp32."""
+    def cubic(x, a=-0.5):
+        ax = abs(x)
+        if ax <= 1:
+            return (a + 2) * ax ** 3 - (a + 3) * ax ** 2 + 1
+        if 1 < ax < 2:
+            return a * ax ** 3 - 5 * a * ax ** 2 + 8 * a * ax - 4 * a
+        return 0
+    k = np.zeros(factor * 4)
+    for i in range(factor * 4):
+        k[i] = cubic((1 / factor) * (i - np.floor(factor * 4 / 2) + 0.5))
+    k = torch.from_numpy(k / np.sum(k)).float()
+    return k / k.sum()

@@ -1,0 +1,280 @@
+"""MI355X engine for the CelebA-HQ noise predictor.
+
+Drop-in for the reference's `guided_diffusion/models.py::Model` (:192-341): same
+constructor argument (the YAML config namespace), same `state_dict` key names
+(so `load_state_dict(torch.load("celeba_hq.ckpt"))` works unchanged), same call
+protocol `model(x[B,3,R,R], t[B]) -> eps[B,3,R,R]` (NCHW fp32).
+
+Inside, nothing is a torch op.  Activations live in HBM as NHWC fp32 and every
+layer is a launch of a hand-written HIP kernel (ddnm_amd/csrc):
+
+  * conv3x3 / conv1x1 / strided conv  -> implicit GEMM on v_mfma_f32_32x32x2_f32;
+    its A-tile loader folds in GroupNorm-affine + swish, nearest x2 upsampling and
+    the skip-connection concat (two source pointers); its epilogue folds in the
+    bias, the timestep-embedding projection and the residual add.
+  * GroupNorm                          -> statistics kernel only (one read of the
+    tensor); the normalised tensor is never written.
+  * attention (1 head, d=512)          -> fused qkv 1x1 conv, QK^T and PV on MFMA,
+    wave-shuffle softmax.
+  * all 32 `temb_proj` Linears         -> ONE launch per step (they share swish(temb)).
+
+Layer order restates models.py:301-341 (forward), :115-134 (ResnetBlock),
+:165-189 (AttnBlock), :61-71 (Downsample), :47-51 (Upsample).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+
+GN_EPS = 1e-6          # models.py:33
+CIN_PAD = 32           # conv_in reads the image through a 32-channel NHWC staging tensor
+
+
+class _ResBlock:
+    def __init__(self, name, cin, cout):
+        self.name, self.cin, self.cout = name, cin, cout
+        self.temb_off = None
+
+
+class _Attn:
+    def __init__(self, name, c):
+        self.name, self.c = name, c
+
+
+class Model:
+    def __init__(self, config, device=None):
+        self.config = config
+        m = config.model
+        self.ch, self.out_ch, self.ch_mult = m.ch, m.out_ch, tuple(m.ch_mult)
+        self.num_res_blocks = m.num_res_blocks
+        self.attn_resolutions = list(m.attn_resolutions)
+        self.in_channels = m.in_channels
+        self.resolution = config.data.image_size
+        self.temb_ch = 4 * self.ch
+        self.num_resolutions = len(self.ch_mult)
+        if not m.resamp_with_conv:
+            raise NotImplementedError("resamp_with_conv=False is not on the DDNM hot path")
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        self._plan()
+        self.w = None
+
+    # ------------------------------------------------------------------ structure
+    def _plan(self):
+        ch, mult, nrb = self.ch, self.ch_mult, self.num_res_blocks
+        in_mult = (1,) + mult
+        res = self.resolution
+        self.down = []
+        self.res_blocks = []          # execution order (defines the temb_proj concat layout)
+        block_in = None
+        chans = [ch]
+        for lvl in range(self.num_resolutions):
+            block_in = ch * in_mult[lvl]
+            block_out = ch * mult[lvl]
+            blocks, attns = [], []
+            for ib in range(nrb):
+                rb = _ResBlock(f"down.{lvl}.block.{ib}", block_in, block_out)
+                blocks.append(rb)
+                self.res_blocks.append(rb)
+                block_in = block_out
+                if res in self.attn_resolutions:
+                    attns.append(_Attn(f"down.{lvl}.attn.{ib}", block_in))
+                chans.append(block_in)
+            has_down = lvl != self.num_resolutions - 1
+            if has_down:
+                res //= 2
+                chans.append(block_in)
+            self.down.append((blocks, attns, has_down, block_in))
+        self.mid = [_ResBlock("mid.block_1", block_in, block_in), _Attn("mid.attn_1", block_in),
+                    _ResBlock("mid.block_2", block_in, block_in)]
+        self.res_blocks += [self.mid[0], self.mid[2]]
+        self.up = {}
+        for lvl in reversed(range(self.num_resolutions)):
+            block_out = ch * mult[lvl]
+            blocks, attns = [], []
+            for ib in range(nrb + 1):
+                skip = chans.pop()
+                rb = _ResBlock(f"up.{lvl}.block.{ib}", block_in + skip, block_out)
+                rb.split = (block_in, skip)
+                blocks.append(rb)
+                self.res_blocks.append(rb)
+                block_in = block_out
+                if res in self.attn_resolutions:
+                    attns.append(_Attn(f"up.{lvl}.attn.{ib}", block_in))
+            has_up = lvl != 0
+            if has_up:
+                res *= 2
+            self.up[lvl] = (blocks, attns, has_up, block_in)
+        self.final_ch = block_in
+        off = 0
+        for rb in self.res_blocks:
+            rb.temb_off = off
+            off += rb.cout
+        self.temb_total = off
+        self.max_ch = max(rb.cin for rb in self.res_blocks)
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def state_dict_keys(self):
+        """Keys this engine consumes (== reference Model.state_dict().keys())."""
+        keys = ["temb.dense.0", "temb.dense.1", "conv_in"]
+        out = []
+        for k in keys:
+            out += [k + ".weight", k + ".bias"]
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        dev = self.device
+        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
+        w = {}
+        for k in ("temb.dense.0", "temb.dense.1"):
+            w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
+        w["conv_in.weight"] = ops.pack_conv_weight(g("conv_in.weight"), cin_pad=CIN_PAD)
+        w["conv_in.bias"] = g("conv_in.bias")
+        tw, tb = [], []
+        for rb in self.res_blocks:
+            n = rb.name
+            for norm in ("norm1", "norm2"):
+                w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
+            w[f"{n}.conv1.weight"] = ops.pack_conv_weight(g(f"{n}.conv1.weight"))
+            w[f"{n}.conv2.weight"] = ops.pack_conv_weight(g(f"{n}.conv2.weight"))
+            w[f"{n}.conv2.bias"] = g(f"{n}.conv2.bias")
+            # conv1 bias folded into the (concatenated) temb projection: h = conv1(.) + b1 + proj(temb)
+            tw.append(g(f"{n}.temb_proj.weight"))
+            tb.append(g(f"{n}.temb_proj.bias") + g(f"{n}.conv1.bias"))
+            if rb.cin != rb.cout:
+                w[f"{n}.nin_shortcut.weight"] = ops.pack_conv_weight(g(f"{n}.nin_shortcut.weight"))
+                w[f"{n}.nin_shortcut.bias"] = g(f"{n}.nin_shortcut.bias")
+        w["temb_proj_cat.weight"] = torch.cat(tw, 0).contiguous()
+        w["temb_proj_cat.bias"] = torch.cat(tb, 0).contiguous()
+        attns = [a for (_, at, _, _) in self.down for a in at] + [self.mid[1]] + \
+                [a for lvl in self.up for a in self.up[lvl][1]]
+        for a in attns:
+            n = a.name
+            w[f"{n}.norm.weight"], w[f"{n}.norm.bias"] = g(f"{n}.norm.weight"), g(f"{n}.norm.bias")
+            wq = torch.cat([g(f"{n}.{p}.weight") for p in ("q", "k", "v")], 0)
+            w[f"{n}.qkv.weight"] = ops.pack_conv_weight(wq)
+            w[f"{n}.qkv.bias"] = torch.cat([g(f"{n}.{p}.bias") for p in ("q", "k", "v")], 0).contiguous()
+            w[f"{n}.proj_out.weight"] = ops.pack_conv_weight(g(f"{n}.proj_out.weight"))
+            w[f"{n}.proj_out.bias"] = g(f"{n}.proj_out.bias")
+        for lvl, (_, _, has_down, c) in enumerate(self.down):
+            if has_down:
+                w[f"down.{lvl}.downsample.conv.weight"] = ops.pack_conv_weight(g(f"down.{lvl}.downsample.conv.weight"))
+                w[f"down.{lvl}.downsample.conv.bias"] = g(f"down.{lvl}.downsample.conv.bias")
+        for lvl, (_, _, has_up, c) in self.up.items():
+            if has_up:
+                w[f"up.{lvl}.upsample.conv.weight"] = ops.pack_conv_weight(g(f"up.{lvl}.upsample.conv.weight"))
+                w[f"up.{lvl}.upsample.conv.bias"] = g(f"up.{lvl}.upsample.conv.bias")
+        w["norm_out.weight"], w["norm_out.bias"] = g("norm_out.weight"), g("norm_out.bias")
+        w["conv_out.weight"] = ops.pack_conv_weight(g("conv_out.weight"))
+        w["conv_out.bias"] = g("conv_out.bias")
+        half = self.ch // 2
+        freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))   # models.py:16-17
+        w["temb.freq"] = freq.to(dev)
+        self.w = w
+        self._ws = None
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, B):
+        if self._ws is None or self._ws_B < B:
+            r = self.resolution
+            max_partial = 0
+            # bound over the (HW, C) pairs that occur: C <= max_ch at every resolution
+            res = r
+            for _ in range(self.num_resolutions):
+                for c in (self.ch, self.max_ch):
+                    max_partial = max(max_partial, ops.gn_nchunk(res * res, c))
+                res //= 2
+            self._ws = ops.GroupNormWorkspace(self.device, B, self.max_ch, B * max_partial * 32 * 2)
+            self._ws_B = B
+        return self._ws
+
+    def _gn(self, x0, x1, name):
+        return ops.group_norm_affine(x0, x1, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws)
+
+    def _resblock(self, rb, x0, x1, tproj):
+        w, n = self.w, rb.name
+        gn1 = self._gn(x0, x1, n + ".norm1")
+        h = ops.conv2d(x0, w[n + ".conv1.weight"], rb.cout, 3, src1=x1, gn=gn1, gn_silu=True,
+                       badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total)
+        gn2 = self._gn(h, None, n + ".norm2")
+        if rb.cin != rb.cout:
+            xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"])
+        else:
+            assert x1 is None
+            xs = x0
+        return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True, bias=w[n + ".conv2.bias"],
+                          res=xs)
+
+    def _attn(self, a, x):
+        w, n = self.w, a.name
+        B, H, W, C = x.shape
+        T = H * W
+        gn = self._gn(x, None, n + ".norm")
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        S = torch.empty(B, T, T, dtype=torch.float32, device=x.device)
+        q, k, v = qkv.view(-1)[0:], qkv.view(-1)[C:], qkv.view(-1)[2 * C:]
+        ops.bgemm(q, k, S, T, T, C, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B,
+                  sA=(T * 3 * C, 0), sB=(T * 3 * C, 0), sC=(T * T, 0))
+        ops.softmax_rows_(S, B * T, T, T, float(int(C) ** (-0.5)))
+        o = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        ops.bgemm(S, v, o, T, C, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B,
+                  sA=(T * T, 0), sB=(T * 3 * C, 0), sC=(T * C, 0))
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+
+    def forward(self, x, t):
+        if self.w is None:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        assert x.shape[2] == x.shape[3] == self.resolution
+        w = self.w
+        B = x.shape[0]
+        self._workspace(B)
+        t = t.to(device=x.device, dtype=torch.float32).contiguous()
+        emb = ops.timestep_embedding(t, w["temb.freq"], order=0)
+        temb = ops.linear(emb, w["temb.dense.0.weight"], w["temb.dense.0.bias"])
+        temb = ops.linear(temb, w["temb.dense.1.weight"], w["temb.dense.1.bias"], silu_in=True)
+        tproj = ops.linear(temb, w["temb_proj_cat.weight"], w["temb_proj_cat.bias"], silu_in=True)
+
+        xin = ops.nchw_to_nhwc_pad(x.contiguous(), CIN_PAD)
+        hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"])]
+        for lvl, (blocks, attns, has_down, c) in enumerate(self.down):
+            for ib, rb in enumerate(blocks):
+                h = self._resblock(rb, hs[-1], None, tproj)
+                if attns:
+                    h = self._attn(attns[ib], h)
+                hs.append(h)
+            if has_down:
+                n = f"down.{lvl}.downsample.conv"
+                src = hs[-1]
+                # F.pad(x, (0,1,0,1)) + 3x3 stride 2 (models.py:68-71): pad=0 on top/left, the
+                # bottom/right zero row/column comes from the loader's bounds check
+                hs.append(ops.conv2d(src, w[n + ".weight"], c, 3, bias=w[n + ".bias"], stride=2, pad=0,
+                                     out_hw=(src.shape[1] // 2, src.shape[2] // 2)))
+        h = hs[-1]
+        h = self._resblock(self.mid[0], h, None, tproj)
+        h = self._attn(self.mid[1], h)
+        h = self._resblock(self.mid[2], h, None, tproj)
+        for lvl in reversed(range(self.num_resolutions)):
+            blocks, attns, has_up, c = self.up[lvl]
+            for ib, rb in enumerate(blocks):
+                h = self._resblock(rb, h, hs.pop(), tproj)
+                if attns:
+                    h = self._attn(attns[ib], h)
+            if has_up:
+                n = f"up.{lvl}.upsample.conv"
+                h = ops.conv2d(h, w[n + ".weight"], c, 3, bias=w[n + ".bias"], ups=True)
+        gn = self._gn(h, None, "norm_out")
+        return ops.conv2d(h, w["conv_out.weight"], self.out_ch, 3, gn=gn, gn_silu=True, bias=w["conv_out.bias"],
+                          out_nchw=True)
+
+    __call__ = forward

@@ -1,0 +1,212 @@
+"""Tensor-level wrappers over the C ABI (ddnm_amd/_lib.py).
+
+PyTorch-ROCm is used here only as the owner of device memory and of the HIP
+stream; every computation below is a hand-written HIP kernel from
+ddnm_amd/csrc.  Nothing in this module falls back to torch ops.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, GemmDesc, StepScalars, check
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"{name}: expected a contiguous float32 device tensor, got {t.dtype} "
+                         f"contiguous={t.is_contiguous()} device={t.device}")
+    return t
+
+
+# ----------------------------------------------------------------------------- convolution
+CONV_COUT_ALIGN = 128
+
+
+def pack_conv_weight(w, cin_pad=None):
+    """OIHW [Cout,Cin,k,k] -> (O, ky, kx, I) with Cout padded to 128 and Cin to `cin_pad`."""
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin if cin_pad is None else cin_pad
+    cout_pad = (cout + CONV_COUT_ALIGN - 1) // CONV_COUT_ALIGN * CONV_COUT_ALIGN
+    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=torch.float32, device=w.device)
+    out[:cout, :, :cin] = w.float().permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.contiguous()
+
+
+def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, gn=None,
+           gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0):
+    """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc."""
+    B, Hs, Ws, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    Hin, Win = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    if pad is None:
+        pad = ksize // 2
+    if out_hw is None:
+        Ho, Wo = (Hin // stride, Win // stride)
+    else:
+        Ho, Wo = out_hw
+    if out is None:
+        shape = (B, cout, Ho, Wo) if out_nchw else (B, Ho, Wo, cout)
+        out = torch.empty(shape, dtype=torch.float32, device=src0.device)
+    d = ConvDesc()
+    d.src0, d.src1, d.weight = _p(_f32c(src0, "src0")), _p(src1), _p(_f32c(weight, "weight"))
+    d.bias, d.badd, d.res = _p(bias), _p(badd), _p(res)
+    d.gn_scale, d.gn_shift = (None, None) if gn is None else (_p(gn[0]), _p(gn[1]))
+    d.out = _p(out)
+    d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, Hin, Win, C0, C1, cout
+    d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
+    d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
+    d.badd_stride, d.tile = badd_stride, tile
+    check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- GroupNorm
+class GroupNormWorkspace:
+    """Scratch shared by every GroupNorm of a forward pass (stream order makes reuse safe)."""
+
+    def __init__(self, device, max_batch, max_channels, max_partial_doubles):
+        self.partial = torch.empty(max_partial_doubles, dtype=torch.float64, device=device)
+        self.scale = torch.empty(max_batch * max_channels, dtype=torch.float32, device=device)
+        self.shift = torch.empty(max_batch * max_channels, dtype=torch.float32, device=device)
+
+
+def gn_nchunk(hw, c):
+    n = _lib.lib().ddnm_gn_nchunk(hw, c)
+    if n <= 0:
+        check(n, "ddnm_gn_nchunk")
+    return n
+
+
+def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32):
+    """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written."""
+    B, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    C, HW = C0 + C1, H * W
+    nchunk = gn_nchunk(HW, C)
+    need = B * nchunk * groups * 2
+    if ws.partial.numel() < need or ws.scale.numel() < B * C:
+        raise ValueError("GroupNorm workspace too small")
+    L = _lib.lib()
+    check(L.ddnm_gn_stats_f32(_p(src0), _p(src1), B, HW, C0, C1, groups, _p(ws.partial), nchunk, _stream()),
+          "ddnm_gn_stats_f32")
+    check(L.ddnm_gn_finalize_f32(_p(ws.partial), nchunk, _p(gamma), _p(beta), B, HW, C, groups, eps, _p(ws.scale),
+                                 _p(ws.shift), _stream()), "ddnm_gn_finalize_f32")
+    return ws.scale, ws.shift
+
+
+# ----------------------------------------------------------------------------- GEMM / softmax / linear
+def bgemm(A, Bm, C, M, N, K, *, lda, ldb, ldc, transb, batch=1, inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
+          D=None, ldd=0, sD=(0, 0), alpha=1.0, beta=0.0):
+    d = GemmDesc()
+    d.A, d.Bm, d.D, d.C = _p(A), _p(Bm), _p(D), _p(C)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldd = M, N, K, lda, ldb, ldc, ldd
+    d.transb, d.batch, d.inner = int(transb), batch, inner
+    d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi, d.sDo, d.sDi = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sD[0], sD[1]
+    d.alpha, d.beta = alpha, beta
+    check(_lib.lib().ddnm_bgemm_f32(ctypes.byref(d), _stream()), "ddnm_bgemm_f32")
+    return C
+
+
+def softmax_rows_(x, rows, n, ld, scale):
+    check(_lib.lib().ddnm_softmax_rows_f32(_p(x), rows, n, ld, scale, _stream()), "ddnm_softmax_rows_f32")
+    return x
+
+
+def linear(x, W, bias, silu_in=False, out=None):
+    B, K = x.shape
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    check(_lib.lib().ddnm_linear_f32(_p(x), _p(W), _p(bias), _p(out), B, K, N, int(silu_in), _stream()),
+          "ddnm_linear_f32")
+    return out
+
+
+def timestep_embedding(t, freq, order):
+    B, half = t.shape[0], freq.shape[0]
+    emb = torch.empty(B, 2 * half, dtype=torch.float32, device=t.device)
+    check(_lib.lib().ddnm_timestep_embedding_f32(_p(t), _p(freq), _p(emb), B, half, order, _stream()),
+          "ddnm_timestep_embedding_f32")
+    return emb
+
+
+def nchw_to_nhwc_pad(x, cpad):
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, cpad, dtype=torch.float32, device=x.device)
+    check(_lib.lib().ddnm_nchw_to_nhwc_pad_f32(_p(_f32c(x, "x")), _p(out), B, C, H * W, cpad, _stream()),
+          "ddnm_nchw_to_nhwc_pad_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- sampler step
+def step_scalars(at, at_next, eta, lam=1.0, gamma=1.0):
+    """Host-side scalar terms of one reverse step, evaluated in fp32 exactly like the reference
+    (functions/svd_ddnm.py:57,63-65): `at`, `at_next` are fp32 torch scalars (alpha-bar)."""
+    s = StepScalars()
+    at = at.float()
+    at_next = at_next.float()
+    s.sqrt_1m_at = float((1 - at).sqrt())
+    s.sqrt_at = float(at.sqrt())
+    s.sqrt_at_next = float(at_next.sqrt())
+    c1 = (1 - at_next).sqrt() * eta
+    c2 = (1 - at_next).sqrt() * ((1 - eta ** 2) ** 0.5)
+    if gamma != 1.0:
+        c1, c2 = gamma * c1, gamma * c2
+    s.c1, s.c2, s.lam = float(c1), float(c2), float(lam)
+    return s
+
+
+def _et_args(et):
+    """et may be a [B,3,H,W] view of a [B,6,H,W] learn_sigma output (svd_ddnm.py:54-55)."""
+    if et.dim() != 4 or et.stride(3) != 1 or et.stride(2) != et.shape[3] or et.stride(1) != et.shape[2] * et.shape[3]:
+        raise ValueError("et must be channel-contiguous NCHW")
+    return et.data_ptr(), et.stride(0)
+
+
+def step_x0(xt, et, s, out=None):
+    B = xt.shape[0]
+    chw = xt.numel() // B
+    out = torch.empty_like(xt) if out is None else out
+    ep, es = _et_args(et)
+    check(_lib.lib().ddnm_step_x0_f32(_p(xt), ep, es, _p(out), B, chw, ctypes.byref(s), _stream()), "ddnm_step_x0_f32")
+    return out
+
+
+def step_combine(x0, proj, apy, noise, et, s, out=None):
+    B = x0.shape[0]
+    chw = x0.numel() // B
+    out = torch.empty_like(x0) if out is None else out
+    ep, es = _et_args(et)
+    check(_lib.lib().ddnm_step_combine_f32(_p(x0), _p(proj), _p(apy), _p(noise), ep, es, _p(out), B, chw,
+                                           ctypes.byref(s), _stream()), "ddnm_step_combine_f32")
+    return out
+
+
+def renoise(x0, noise, a, b, out=None):
+    out = torch.empty_like(x0) if out is None else out
+    check(_lib.lib().ddnm_renoise_f32(_p(x0), _p(noise), _p(out), x0.numel(), a, b, _stream()), "ddnm_renoise_f32")
+    return out
+
+
+def finalize_psnr(x, x_orig=None, want_img=True):
+    """inverse_data_transform + per-image PSNR (datasets/__init__.py:218-227, diffusion.py:599-602)."""
+    B = x.shape[0]
+    chw = x.numel() // B
+    img = torch.empty_like(x) if want_img else None
+    sse = torch.empty(B, dtype=torch.float64, device=x.device) if x_orig is not None else None
+    check(_lib.lib().ddnm_finalize_psnr_f32(_p(x), _p(x_orig), _p(img), _p(sse), B, chw, _stream()),
+          "ddnm_finalize_psnr_f32")
+    psnr = None
+    if sse is not None:
+        psnr = 10.0 * torch.log10(1.0 / (sse / chw))
+    return img, psnr

@@ -94,7 +94,8 @@ int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gam
  * batch index i -> (i / inner, i % inner); offset = outer*stride_o + inner*stride_i per operand.
  * Replaces torch.bmm / einsum in attention (models.py:171-185; unet.py:344-354) and the
  * separable A / A^+ products of SRConv (functions/svd_operators.py:853-859,893-900).
- * M, N multiples of 64; K multiple of 32.
+ * MFMA path: M, N multiples of 64, K multiple of 32, 16-byte aligned rows; any other shape runs a
+ * scalar fallback kernel (tiny test sizes only).
  * ------------------------------------------------------------------------- */
 typedef struct ddnm_gemm_desc {
     const float* A; const float* Bm; const float* D; float* C;

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+    config.addinivalue_line("markers", "slow: takes more than ~20 s on CPU")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The loaded C-ABI library; GPU tests fail loudly (never skip) if it is missing."""
+    import torch
+    from ddnm_amd import _lib
+    assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
+    return _lib.lib()

@@ -1,0 +1,261 @@
+"""Per-kernel parity on the GPU: every HIP kernel, called through the C ABI, against the
+same op evaluated by torch on CPU in fp32 (the oracle arithmetic)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # B, Cin, Cout, H, k, stride, tile
+    (2, 128, 128, 32, 3, 1, 0),
+    (1, 128, 128, 16, 3, 1, 1),
+    (2, 128, 256, 16, 3, 1, 2),
+    (2, 256, 128, 16, 1, 1, 0),
+    (1, 64, 96, 16, 3, 1, 2),      # Cout not a multiple of the N tile
+    (2, 128, 128, 32, 3, 2, 0),    # Downsample: pad (0,1,0,1), stride 2
+    (1, 32, 128, 32, 3, 1, 0),     # conv_in (image staged to 32 channels)
+    (2, 128, 3, 32, 3, 1, 0),      # conv_out, tile 128x32
+    (8, 512, 512, 8, 3, 1, 0),     # 8x8 level: M tile = one image
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,stride,tile", CONV_CASES)
+def test_conv_plain(hip, B, Cin, Cout, H, k, stride, tile):
+    from ddnm_amd import ops
+    x = gen(B, Cin, H, H, seed=1)
+    w = gen(Cout, Cin, k, k, seed=2, scale=(Cin * k * k) ** -0.5)
+    b = gen(Cout, seed=3)
+    if stride == 2:
+        ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+        out = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w.cuda()), Cout, k, bias=b.cuda(), stride=2, pad=0,
+                         out_hw=(H // 2, H // 2), tile=tile)
+    else:
+        ref = F.conv2d(x, w, b, padding=k // 2)
+        out = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w.cuda()), Cout, k, bias=b.cuda(), tile=tile)
+    torch.cuda.synchronize()
+    assert rel(nchw(out.cpu()), ref) < 2e-6
+
+
+def test_conv_fused_everything(hip):
+    """GN-affine+swish prologue, concat of two sources, nearest-x2 upsample, temb addend, residual."""
+    from ddnm_amd import ops
+    B, C0, C1, Cout, Hs = 2, 128, 64, 128, 8
+    a, bsrc = gen(B, C0, Hs, Hs, seed=4), gen(B, C1, Hs, Hs, seed=5)
+    w = gen(Cout, C0 + C1, 3, 3, seed=6, scale=(9 * (C0 + C1)) ** -0.5)
+    bias, badd = gen(Cout, seed=7), gen(B, 300, seed=8)
+    scale, shift = gen(B, C0 + C1, seed=9), gen(B, C0 + C1, seed=10)
+    res = gen(B, Cout, 2 * Hs, 2 * Hs, seed=11)
+    xin = torch.cat([a, bsrc], 1)
+    act = xin * scale[:, :, None, None] + shift[:, :, None, None]
+    act = act * torch.sigmoid(act)
+    act = F.interpolate(act, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(act, w, bias, padding=1) + badd[:, 100:100 + Cout, None, None] + res
+    out = ops.conv2d(nhwc(a).cuda(), ops.pack_conv_weight(w.cuda()), Cout, 3, src1=nhwc(bsrc).cuda(), bias=bias.cuda(),
+                     badd=badd.cuda()[:, 100:], badd_stride=300, res=nhwc(res).cuda(),
+                     gn=(scale.cuda().contiguous(), shift.cuda().contiguous()), gn_silu=True, ups=True)
+    torch.cuda.synchronize()
+    assert rel(nchw(out.cpu()), ref) < 3e-6
+
+
+def test_conv_nchw_out(hip):
+    from ddnm_amd import ops
+    x = gen(2, 128, 32, 32, seed=12)
+    w = gen(3, 128, 3, 3, seed=13, scale=0.03)
+    b = gen(3, seed=14)
+    out = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w.cuda()), 3, 3, bias=b.cuda(), out_nchw=True)
+    torch.cuda.synchronize()
+    assert out.shape == (2, 3, 32, 32)
+    assert rel(out.cpu(), F.conv2d(x, w, b, padding=1)) < 2e-6
+
+
+def test_conv_rejects_bad_shapes(hip):
+    from ddnm_amd import ops
+    from ddnm_amd._lib import DDNMHipError
+    x = torch.zeros(1, 8, 8, 48, device="cuda")       # C0 % 32 != 0
+    with pytest.raises(DDNMHipError):
+        ops.conv2d(x, torch.zeros(128, 9, 48, device="cuda"), 128, 3)
+
+
+# ------------------------------------------------------------------ GroupNorm
+@pytest.mark.parametrize("B,C0,C1,H", [(2, 128, 0, 32), (2, 256, 128, 16), (1, 512, 256, 8), (3, 1024, 0, 8),
+                                       (1, 128, 0, 64)])
+def test_groupnorm_affine(hip, B, C0, C1, H):
+    from ddnm_amd import ops
+    a = gen(B, C0, H, H, seed=20) * 2 + 0.7
+    b2 = gen(B, C1, H, H, seed=21) if C1 else None
+    C = C0 + C1
+    gamma, beta = 1 + 0.1 * gen(C, seed=22), 0.1 * gen(C, seed=23)
+    xin = a if b2 is None else torch.cat([a, b2], 1)
+    ref = F.group_norm(xin, 32, gamma, beta, eps=1e-6)
+    ws = ops.GroupNormWorkspace("cuda", B, C, B * ops.gn_nchunk(H * H, C) * 64)
+    sc, sh = ops.group_norm_affine(nhwc(a).cuda(), None if b2 is None else nhwc(b2).cuda(), gamma.cuda(), beta.cuda(),
+                                   1e-6, ws)
+    torch.cuda.synchronize()
+    sc, sh = sc[:B * C].reshape(B, C).cpu(), sh[:B * C].reshape(B, C).cpu()
+    got = xin * sc[:, :, None, None] + sh[:, :, None, None]
+    assert rel(got, ref) < 2e-6
+
+
+# ------------------------------------------------------------------ GEMM / softmax / linear / embedding
+@pytest.mark.parametrize("M,N,K,transb,batch", [(64, 64, 512, True, 3), (256, 256, 512, True, 2),
+                                                (256, 512, 256, False, 2), (64, 256, 256, False, 6),
+                                                (16, 16, 64, True, 2), (8, 32, 32, False, 3),
+                                                (256, 256, 64, True, 24)])
+def test_bgemm(hip, M, N, K, transb, batch):
+    from ddnm_amd import ops
+    A = gen(batch, M, K, seed=30)
+    Bm = gen(batch, N, K, seed=31) if transb else gen(batch, K, N, seed=31)
+    D = gen(batch, M, N, seed=32)
+    ref = 0.5 * torch.bmm(A, Bm.transpose(1, 2) if transb else Bm) - D
+    C = torch.empty(batch, M, N, device="cuda")
+    ops.bgemm(A.cuda(), Bm.cuda(), C, M, N, K, lda=K, ldb=K if transb else N, ldc=N, transb=transb, batch=batch,
+              sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), D=D.cuda(), ldd=N, sD=(M * N, 0), alpha=0.5, beta=-1.0)
+    torch.cuda.synchronize()
+    assert rel(C.cpu(), ref) < 2e-6
+
+
+def test_bgemm_shared_operand_and_inner_stride(hip):
+    from ddnm_amd import ops
+    A = gen(64, 256, seed=33)                      # shared across the batch (stride 0)
+    X = gen(2, 3, 256, 256, seed=34)
+    ref = torch.matmul(A, X)
+    C = torch.empty(2, 3, 64, 256, device="cuda")
+    ops.bgemm(A.cuda(), X.cuda(), C, 64, 256, 256, lda=256, ldb=256, ldc=256, transb=False, batch=6, inner=3,
+              sB=(3 * 256 * 256, 256 * 256), sC=(3 * 64 * 256, 64 * 256))
+    torch.cuda.synchronize()
+    assert rel(C.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("n", [64, 256, 1024, 100])
+def test_softmax_rows(hip, n):
+    from ddnm_amd import ops
+    x = gen(37, n, seed=35) * 3
+    got = ops.softmax_rows_(x.cuda().contiguous(), 37, n, n, 0.25)
+    torch.cuda.synchronize()
+    assert rel(got.cpu(), F.softmax(x * 0.25, dim=1)) < 2e-6
+
+
+@pytest.mark.parametrize("silu", [False, True])
+def test_linear(hip, silu):
+    from ddnm_amd import ops
+    x, W, b = gen(5, 512, seed=36), gen(300, 512, seed=37, scale=0.05), gen(300, seed=38)
+    xin = x * torch.sigmoid(x) if silu else x
+    got = ops.linear(x.cuda(), W.cuda(), b.cuda(), silu_in=silu)
+    torch.cuda.synchronize()
+    assert rel(got.cpu(), F.linear(xin, W, b)) < 2e-6
+
+
+def test_timestep_embedding(hip):
+    from ddnm_amd import ops
+    from oracle import unet_celeba
+    import math
+    t = torch.tensor([990.0, 430.0, 0.0, 10.0])
+    half = 64
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    got = ops.timestep_embedding(t.cuda(), freq.cuda(), 0)
+    torch.cuda.synchronize()
+    assert (got.cpu() - unet_celeba.timestep_embedding(t, 128)).abs().max().item() < 2e-4   # sin(990) cond.
+    got1 = ops.timestep_embedding(t.cuda(), freq.cuda(), 1).cpu()
+    assert torch.equal(got1[:, :half], got.cpu()[:, half:]) and torch.equal(got1[:, half:], got.cpu()[:, :half])
+
+
+def test_nchw_to_nhwc_pad(hip):
+    from ddnm_amd import ops
+    x = gen(2, 3, 16, 16, seed=39)
+    got = ops.nchw_to_nhwc_pad(x.cuda(), 32).cpu()
+    assert torch.equal(got[..., :3], nhwc(x)) and got[..., 3:].abs().max().item() == 0.0
+
+
+# ------------------------------------------------------------------ operators (A, A^+) vs oracle
+@pytest.mark.parametrize("name", ["sr_averagepooling", "sr_bicubic", "colorization", "inpainting",
+                                  "cs_walshhadamard", "denoising"])
+@pytest.mark.parametrize("d", [64, 256])
+def test_operator_A_and_pinv(hip, name, d, golden_dir):
+    from oracle import cases
+    from tests.helpers import engine_operator, real_mask
+    mask = real_mask(golden_dir) if (name == "inpainting" and d == 256) else None
+    orc = cases.make_operator(name, d, mask)
+    eng = engine_operator(name, d, mask)
+    x = cases.operator_input(d, 2)
+    y_o = orc.A(x)
+    y_e = eng.A(x.cuda())
+    p_o = orc.A_pinv(y_o)
+    p_e = eng.A_pinv(y_o.cuda())
+    torch.cuda.synchronize()
+    assert y_e.shape == y_o.shape and p_e.shape == p_o.shape
+    assert rel(y_e, y_o) < 3e-6 and rel(p_e, p_o) < 3e-6
+    # golden from the real reference classes
+    g = np.load(f"{golden_dir}/operators.npz")
+    gy = torch.from_numpy(g[f"{name}_{d}_y"])
+    if d == 64:
+        assert rel(y_e, gy) < 3e-6
+        assert rel(p_e.reshape(2, 3, d, d), torch.from_numpy(g[f"{name}_{d}_pinv"])) < 3e-6
+    else:
+        assert rel(y_e.cpu()[:, ::31], gy) < 3e-6
+        assert rel(p_e.cpu().reshape(2, 3, d, d)[..., ::8, ::8], torch.from_numpy(g[f"{name}_{d}_pinv"])) < 3e-6
+    # Moore-Penrose property A A^+ y = y (SURVEY.md section 4 invariants)
+    assert rel(eng.A(p_e), y_o) < 1e-5
+
+
+# ------------------------------------------------------------------ sampler step kernels vs oracle
+@pytest.mark.parametrize("name", ["sr_averagepooling", "sr_bicubic", "colorization", "inpainting",
+                                  "cs_walshhadamard", "denoising"])
+@pytest.mark.parametrize("six", [False, True])
+def test_ddnm_step(hip, name, six):
+    from ddnm_amd import ops
+    from oracle import cases, schedule
+    from tests.helpers import engine_operator
+    d, B = 64, 2
+    orc, eng = cases.make_operator(name, d), engine_operator(name, d)
+    xt, et6, nz = gen(B, 3, d, d, seed=40), gen(B, 6, d, d, seed=41), gen(B, 3, d, d, seed=42)
+    et = et6[:, :3]
+    y = orc.A(gen(B, 3, d, d, seed=43))
+    betas = cases.betas()
+    at, at_next = schedule.alpha_bar(betas, 500), schedule.alpha_bar(betas, 490)
+    eta = 0.85
+    x0 = (xt - et * (1 - at).sqrt()) / at.sqrt()
+    x0h = x0 - orc.A_pinv(orc.A(x0.reshape(B, -1)) - y).reshape(x0.shape)
+    ref = at_next.sqrt() * x0h + (1 - at_next).sqrt() * eta * nz + (1 - at_next).sqrt() * ((1 - eta ** 2) ** 0.5) * et
+    s = ops.step_scalars(at, at_next, eta)
+    et_dev = et6.cuda()[:, :3] if six else et.contiguous().cuda()
+    x0_e, out = torch.empty(B, 3, d, d, device="cuda"), torch.empty(B, 3, d, d, device="cuda")
+    eng.ddnm_step(xt.cuda(), et_dev, nz.cuda(), y.cuda(), s, x0_e, out)
+    torch.cuda.synchronize()
+    assert rel(x0_e, x0) < 1e-6
+    assert rel(out, ref) < 3e-6
+    if name in ("sr_averagepooling", "denoising", "inpainting"):
+        assert torch.equal(x0_e.cpu(), x0), "x0 must be bit-exact (same fp32 evaluation order)"
+
+
+def test_renoise_and_finalize(hip):
+    from ddnm_amd import ops
+    from oracle import sampler
+    x0, nz, xo = gen(2, 3, 32, 32, seed=44), gen(2, 3, 32, 32, seed=45), gen(2, 3, 32, 32, seed=46)
+    got = ops.renoise(x0.cuda(), nz.cuda(), 0.8, 0.6)
+    img, psnr = ops.finalize_psnr(x0.cuda(), xo.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), 0.8 * x0 + nz * 0.6)
+    assert torch.equal(img.cpu(), torch.clamp((x0 + 1.0) / 2.0, 0.0, 1.0))
+    assert (psnr.cpu().float() - sampler.psnr(x0, xo)).abs().max().item() < 1e-4
