@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: restored images/sec @256x256, 100 DDIM steps, 4x SR (BASELINE.json).
+
+Workload at N=1 = BASELINE config 2: celeba_hq `Model` (fp32, 113.67 M params, 498.35 GFLOP per
+forward per image), `sr_bicubic` 4x (SRConv), sigma_y = 0, eta = 0.85, T_sampling = 100,
+batch_size = 8 per GPU.  One bench "step" = one full pass of the hot path over one batch:
+x_T on device -> 100 reverse steps (UNet forward + projection + DDIM update) -> x_0 on device.
+Synthetic inputs, seeded random weights of the real architecture (no checkpoints offline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: one process per GPU, every rank restores its own batch of 8 (weak scaling), one RCCL
+all_gather of the restored images at the end of each step (inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
+FLOPS_PER_FWD_PER_IMAGE = 498.35e9   # SURVEY.md section 8(d), celeba Model
+T_SAMPLING = 100
+BATCH_PER_GPU = 8
+
+
+def make_config():
+    import types
+    ns = types.SimpleNamespace
+    return ns(
+        model=ns(type="simple", in_channels=3, out_ch=3, ch=128, ch_mult=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
+                 attn_resolutions=[16], dropout=0.0, var_type="fixedsmall", ema_rate=0.999, ema=True,
+                 resamp_with_conv=True),
+        data=ns(dataset="CelebA_HQ", image_size=256, channels=3, rescaled=True, logit_transform=False,
+                uniform_dequantization=False, gaussian_dequantization=False),
+        diffusion=ns(beta_schedule="linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000),
+        time_travel=ns(T_sampling=T_SAMPLING, travel_length=1, travel_repeat=1),
+        sampling=ns(batch_size=BATCH_PER_GPU))
+
+
+def cpu_baseline(cfg, sd, n_steps=4):
+    """Reported baseline: the oracle restatement of the reference path (bit-identical to the reference
+    UNet on CPU, tests/test_oracle_pins.py) on this box's host cores.  Bounded sample: B=1,
+    `n_steps` reverse steps of the 100, extrapolated."""
+    from oracle import cases, sampler, unet_celeba
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    x_orig, x_T, tape = cases.sampler_case(cfg, 1, T_SAMPLING)
+    op = cases.make_operator("sr_bicubic", 256)
+    y = op.A(x_orig)
+    net = unet_celeba.Net(sd, cfg)
+    net(x_T, torch.tensor([990.0]))          # warm-up forward
+
+    class Stop(Exception):
+        pass
+
+    t0 = [None]
+
+    def record(k, name, t):
+        if name == "xt_next" and k == n_steps - 1:
+            raise Stop
+
+    t0 = time.perf_counter()
+    try:
+        sampler.ddnm_diffusion(x_T, net, cases.betas(), 0.85, op, y, tape, record=record)
+    except Stop:
+        pass
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"B=1, {n_steps} of {T_SAMPLING} reverse steps timed ({dt:.1f} s), x{T_SAMPLING // n_steps} extrapolated"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from ddnm_amd import dist as ddist
+    from ddnm_amd import ops
+    from ddnm_amd.functions.svd_ddnm import ddnm_diffusion
+    from ddnm_amd.functions.svd_operators import build_operator
+    from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
+    from ddnm_amd.guided_diffusion.models import Model
+
+    rank, local_rank, world = ddist.init()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE\n")
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    cfg = make_config()
+    model = Model(cfg, device=dev)
+    sd = model.random_state_dict(seed=1234)          # identical replica on every rank, no broadcast
+    model.load_state_dict(sd)
+    betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
+                                               num_diffusion_timesteps=1000)).float().to(dev)
+    op = build_operator("sr_bicubic", 4, cfg, dev)
+    B = BATCH_PER_GPU
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x_orig = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
+    y = op.A(x_orig)
+    torch.cuda.manual_seed(1234 + rank)
+
+    def one_pass():
+        x_T = torch.randn(B, 3, 256, 256, device=dev)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg)
+        return ddist.gather_images(xs[0])            # the path's single collective
+
+    for _ in range(args.warmup):
+        out = one_pass()
+    ddist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    ddist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = tmax.item()
+    assert out.shape[0] == B * world and bool(torch.isfinite(out).all())
+    # data-consistency spot check of the last pass (this rank's slice): A x_0 = y
+    mine = out[rank * B:(rank + 1) * B]
+    resid = (op.A(mine) - y).abs().max().item()
+
+    value = args.steps * B * world / dt
+    line = {
+        "metric": "restored images/sec @256x256, 100 DDIM steps, 4x SR", "value": round(value, 4),
+        "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "celeba_hq.yml SVD sr_bicubic 4x, sigma_y=0, eta=0.85, T_sampling=100, "
+                               "batch_size=8 per GPU (BASELINE configs[1])",
+                   "global_batch": B * world, "image": "3x256x256", "parallelism": f"dp{world} (image sharding)"},
+        "consistency_max_abs": resid,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel: the 128x128-tile implicit-GEMM convolution.  One more, instrumented pass of
+        # the same workload: HIP events around every convolution launch on the launch stream.
+        timer = ops.KernelTimer()
+        ops.set_kernel_timer(timer)
+        x_T = torch.randn(B, 3, 256, 256, device=dev)
+        t = torch.full((B,), 500.0, device=dev)
+        for _ in range(3):
+            model(x_T, t)
+        ops.set_kernel_timer(None)
+        summ = timer.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        name, r = dom
+        total_ms = sum(v["ms"] for v in summ.values())
+        achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        line["roofline"] = {
+            "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+            "avg_flops_per_launch": r["flops"] / r["launches"],
+            "share_of_conv_time": round(r["ms"] / total_ms, 4),
+            "whole_loop_tflops": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world, 2),
+            "whole_loop_frac": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world / PEAK_F32_TFLOPS, 4),
+        }
+    if world > 1:
+        ddist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        ddist.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

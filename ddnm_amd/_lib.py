@@ -24,6 +24,7 @@ class ConvDesc(Structure):
         ("Ho", c_int32), ("Wo", c_int32),
         ("ups", c_int32), ("gn_silu", c_int32), ("out_nchw", c_int32),
         ("badd_stride", c_int32), ("tile", c_int32),
+        ("workspace", c_void_p), ("workspace_floats", c_int64),
     ]
 
 
@@ -50,6 +51,7 @@ PROTOTYPES = {
     "ddnm_error_string": (c_char_p, [c_int32]),
     "ddnm_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_gn_stats_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_int32, c_void_p]),
     "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),
@@ -68,7 +70,7 @@ PROTOTYPES = {
     "ddnm_step_sr_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_int32, c_int32, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
     "ddnm_step_color_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                      c_int32, c_int32, POINTER(StepScalars), c_void_p]),
+                                      c_int32, c_int32, POINTER(c_float), POINTER(StepScalars), c_void_p]),
     "ddnm_step_inpaint_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32,
                                         c_void_p, c_void_p, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
     "ddnm_step_denoise_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -76,8 +78,8 @@ PROTOTYPES = {
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_op_upsample_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "ddnm_op_color_A_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
-    "ddnm_op_color_pinv_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_op_color_A_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
+    "ddnm_op_color_pinv_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "ddnm_op_inpaint_A_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "ddnm_op_inpaint_pinv_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "ddnm_fwht2d_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
@@ -103,6 +105,10 @@ def lib():
             raise DDNMHipError(
                 f"{LIB_PATH} is missing: build it with `python -m ddnm_amd.build` "
                 "(the DDNM hot path has no CPU/PyTorch fallback)")
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Load torch FIRST so the
+        # kernels run in the HIP runtime that owns torch's device memory and streams; loading ours first
+        # would bring up a second runtime and every launch would fail with hipErrorNoDevice.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported

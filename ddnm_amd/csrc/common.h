@@ -11,6 +11,15 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// launch + error check that ignores stale errors left by unrelated runtime calls of the host process
+#define DDNM_LAUNCH(...)                          \
+    do {                                          \
+        (void)hipGetLastError();                  \
+        hipLaunchKernelGGL(__VA_ARGS__);          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -23,7 +32,14 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// swish with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_f(float v) {
+#ifdef DDNM_PROBE_SLOW_SILU
+    return v / (1.0f + __expf(-v));
+#else
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+#endif
+}
 
 // 32x32 MFMA tile step over 8 k-values held as two float4 (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7)
 __device__ __forceinline__ f32x16 mfma_k8(const f32x4 a, const f32x4 b, f32x16 c) {

@@ -2,13 +2,22 @@
 //
 //   GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = taps * Cin.
 //   Workgroup = 256 threads = 4 waves arranged WM x WN; each wave owns MT x NT tiles of 32x32.
-//   K loop: (channel chunk of 32) x (filter tap).  Per step the A tile [BM][32] is gathered
-//   from the NHWC activation(s) -- through the optional nearest-x2 upsample, channel concat
-//   of two sources and GroupNorm-affine(+swish) prologue -- and the B tile [BN][32] from the
-//   (O, ky, kx, I)-packed weights; both land k-contiguous in LDS (row pitch 36 floats), so
-//   each lane fetches its MFMA operands with one conflict-free ds_read_b128 per 4 MFMAs.
-//   Global loads for step i+1 are issued before the MFMAs of step i (register staging).
-//   Epilogue: + bias + per-sample addend (temb projection) + residual, NHWC or NCHW store.
+//   Operands land k-contiguous in LDS (row pitch 36 floats), so each lane fetches its MFMA
+//   operands with one conflict-free ds_read_b128 per 4 MFMAs; global loads for step i+1 are
+//   issued before the MFMAs of step i (register staging).
+//
+// Two kernels share the MFMA core and the epilogue:
+//   * conv3x3_halo  (3x3, stride 1, pad 1 -- >97 % of the UNet's FLOPs): the (TH+2)x(TW+2)
+//     input halo of a TH x TW output tile is staged ONCE per 32-channel chunk -- through the
+//     optional nearest-x2 upsample, channel concat of two sources and GroupNorm-affine(+swish)
+//     prologue -- and the 9 taps read it at shifted LDS rows; only the [BN][32] weight tile is
+//     re-staged per tap.  Activation loads and GN/swish VALU work drop 9x vs per-tap gathering.
+//   * conv_gather   (1x1, strided 3x3 with asymmetric padding): the A tile [BM][32] is gathered
+//     per tap straight from global memory.
+// Split-K: layers with too few output tiles to fill 256 CUs (8x8 .. 32x32 levels) split the
+//   channel chunks over `ksplit` workgroups per tile; partial tiles go to a workspace slab and a
+//   second kernel reduces them in a fixed order (deterministic) and applies the epilogue.
+// Epilogue: + bias + per-sample addend (temb projection) + residual, NHWC or NCHW store.
 //
 // Replaces: nn.Conv2d call sites of guided_diffusion/models.py (see include/ddnm_hip.h).
 #include "common.h"
@@ -17,12 +26,259 @@ struct ConvArgs {
     ddnm_conv_desc d;
     int Cin, ntaps, Hs, Ws;
     int m_tiles, n_tiles;
-    int tiles_x, tiles_per_img;  // 2-D tiling of the output image (tiles_x == 0: flat strips)
-    int TW;                      // tile width in pixels (power of two) in 2-D mode
+    int tiles_x;        // 2-D tiling of the output image (0: flat strips, gather kernel only)
+    int TW, TW_log2;    // tile width in pixels (power of two)
+    int ksplit;         // workgroups per output tile along K (channel chunks)
+    float* ws;          // split-K slabs [ksplit][B*Ho*Wo][Cout]
 };
 
+// ---- tile geometry helper: local row r of M-tile -> output pixel
+struct TileMap {
+    int img, ty0, tx0, th_unused, TW, TW_log2, flat_base, Wo;
+    bool two_d;
+    __device__ __forceinline__ void pixel(int r, int& oy, int& ox) const {
+        if (two_d) {
+            oy = ty0 + (r >> TW_log2);
+            ox = tx0 + (r & (TW - 1));
+        } else {
+            const int pix = flat_base + r;
+            oy = pix / Wo;
+            ox = pix - oy * Wo;
+        }
+    }
+};
+
+template <int BM>
+__device__ __forceinline__ TileMap make_tilemap(const ConvArgs& p, int m_tile) {
+    TileMap t;
+    const int HWo = p.d.Ho * p.d.Wo;
+    const int per_img = HWo / BM;
+    t.img = m_tile / per_img;
+    const int t_in_img = m_tile - t.img * per_img;
+    t.TW = p.TW;
+    t.TW_log2 = p.TW_log2;
+    t.Wo = p.d.Wo;
+    t.two_d = p.tiles_x != 0;
+    if (t.two_d) {
+        const int ty = t_in_img / p.tiles_x, tx = t_in_img - ty * p.tiles_x;
+        t.ty0 = ty * (BM >> p.TW_log2);
+        t.tx0 = tx << p.TW_log2;
+        t.flat_base = 0;
+    } else {
+        t.ty0 = t.tx0 = 0;
+        t.flat_base = t_in_img * BM;
+    }
+    return t;
+}
+
+// ---- shared epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int slice,
+                                              f32x16 (&acc)[MT][NT]) {
+    constexpr int BN = WN * NT * 32;
+    const ddnm_conv_desc& d = p.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ncol = lane & 31, rsel = 4 * (lane >> 5);
+    const bool partial = p.ksplit > 1;
+    float* ws = partial ? p.ws + (size_t)slice * d.B * d.Ho * d.Wo * d.Cout : nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
+        if (n >= d.Cout) continue;
+        float add = 0.f;
+        if (!partial) {
+            if (d.bias) add = d.bias[n];
+            if (d.badd) add += d.badd[(size_t)tm.img * d.badd_stride + n];
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                int oy, ox;
+                tm.pixel(row, oy, ox);
+                float v = acc[i][j][r] + add;
+                const size_t o = ((size_t)(tm.img * d.Ho + oy) * d.Wo + ox) * d.Cout + n;
+                if (partial) {
+                    ws[o] = v;
+                } else if (d.out_nchw) {
+                    d.out[((size_t)(tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox] = v;
+                } else {
+                    if (d.res) v += d.res[o];
+                    d.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mfma_tile_step(const float* a_frag, const float* b_frag, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int kk = 0; kk < KC / 8; ++kk) {
+        f32x4 a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDT + kk * 8);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
+    }
+}
+
+__device__ __forceinline__ f32x4 gn_act(f32x4 v, const f32x4 gsc, const f32x4 gsh, int silu) {
+    v = v * gsc + gsh;
+    if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+    return v;
+}
+
+// =====================================================================================
+// 3x3 stride-1 pad-1 convolution with an LDS-resident input halo
+// =====================================================================================
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p) {
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int MAXH = BM == 128 ? 204 : 136;          // (TH+2)*(TW+2) for TW in {8,16,32}
+    constexpr int HR = (MAXH + 31) / 32;                 // halo rows staged per thread
+    constexpr int BR = BN / 32;
+    __shared__ __attribute__((aligned(16))) float Hs[MAXH * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+
+    const ddnm_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
+    const int slice = blockIdx.y;
+    const TileMap tm = make_tilemap<BM>(p, m_tile);
+    const int img = tm.img;
+    const int TH = BM >> p.TW_log2, HWd = p.TW + 2;
+    const int NP = (TH + 2) * HWd;
+
+    // ---- halo loader mapping: thread -> (float4 column c4, halo rows prow + 32*i)
+    const int c4 = tid & 7, prow = tid >> 3;
+    int hoff[HR];                                         // source pixel index, -1: zero (padding / unused row)
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int row = prow + 32 * i;
+        const int hy = row / HWd, hx = row - hy * HWd;
+        const int iy = tm.ty0 - 1 + hy, ix = tm.tx0 - 1 + hx;
+        const bool ok = row < NP && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+        hoff[i] = ok ? (img * p.Hs + sy) * p.Ws + sx : -1;
+    }
+    const float* wbase = d.weight + (size_t)(n_tile * BN + prow) * 9 * p.Cin + c4 * 4;
+
+    // K range of this workgroup (channel chunks)
+    const int nchunks = p.Cin / KC;
+    const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
+
+    f32x4 h_st[HR], b_st[BR];
+    f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
+    const bool has_gn = d.gn_scale != nullptr;
+
+    auto prefetch_halo = [&](int chunk) {
+        const int cb = chunk * KC;
+        const float* src;
+        int cs, coff;
+        if (cb < d.C0) { src = d.src0; cs = d.C0; coff = cb; }
+        else { src = d.src1; cs = d.C1; coff = cb - d.C0; }
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
+            h_st[i] = v;
+        }
+        if (has_gn) {
+            gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + c4 * 4);
+            gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + c4 * 4);
+        }
+    };
+    auto prefetch_b = [&](int chunk, int tap) {
+        const float* wp = wbase + (size_t)tap * p.Cin + chunk * KC;
+#pragma unroll
+        for (int i = 0; i < BR; ++i) b_st[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * 9 * p.Cin);
+    };
+    auto stage_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const int row = prow + 32 * i;
+            if (row < MAXH) {
+                f32x4 v = h_st[i];
+#ifndef DDNM_PROBE_NO_GN
+                if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+#endif
+                *reinterpret_cast<f32x4*>(&Hs[row * LDT + c4 * 4]) = v;
+            }
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&Bs[(prow + 32 * i) * LDT + c4 * 4]) = b_st[i];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A-fragment base (tap 0,0): lane's output pixel -> halo row
+    int a_off[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 32 + (lane & 31);
+        const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
+        a_off[i] = (ty * HWd + tx) * LDT + (lane >> 5) * 4;
+    }
+    const float* b_frag = Bs + (wn * NT * 32) * LDT + (lane & 31) * LDT + (lane >> 5) * 4;
+
+    if (c_begin < c_end) {
+        prefetch_halo(c_begin);
+        prefetch_b(c_begin, 0);
+    }
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        for (int tap = 0; tap < 9; ++tap) {
+            __syncthreads();                 // previous MFMAs finished reading Bs (and Hs when tap == 0)
+            if (tap == 0) stage_halo();
+            stage_b();
+            __syncthreads();
+            // loads for the next step fly while this step's MFMAs run
+            if (tap < 8) {
+                prefetch_b(chunk, tap + 1);
+            } else if (chunk + 1 < c_end) {
+                prefetch_b(chunk + 1, 0);
+                prefetch_halo(chunk + 1);
+            }
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int tap_off = (ky * HWd + kx) * LDT;
+#pragma unroll
+            for (int kk = 0; kk < KC / 8; ++kk) {
+                f32x4 a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off + kk * 8);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDT + kk * 8);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
+            }
+        }
+    }
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, slice, acc);
+}
+
+// =====================================================================================
+// generic per-tap gather (1x1, strided 3x3)
+// =====================================================================================
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_gather_f32_kernel(const ConvArgs p) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread for the A / B tile copies
     __shared__ __attribute__((aligned(16))) float As[BM * LDT];
@@ -33,31 +289,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
     const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
-    const int HWo = d.Ho * d.Wo;
+    const int slice = blockIdx.y;
+    const TileMap tm = make_tilemap<BM>(p, m_tile);
+    const int img = tm.img;
 
-    // pixel coordinates of local row r of this M tile
-    const int img = (m_tile * BM) / HWo;           // one image per tile (host guarantees HWo % BM == 0)
-    const int t_in_img = m_tile - img * (HWo / BM);
-    auto pixel_of = [&](int r, int& oy, int& ox) {
-        if (p.tiles_x) {
-            const int ty = t_in_img / p.tiles_x, tx = t_in_img - ty * p.tiles_x;
-            const int th = BM / p.TW;
-            oy = ty * th + r / p.TW;
-            ox = tx * p.TW + (r & (p.TW - 1));
-        } else {
-            const int pix = t_in_img * BM + r;
-            oy = pix / d.Wo;
-            ox = pix - oy * d.Wo;
-        }
-    };
-
-    // ---- loader mapping: thread -> (float4 column c4, rows row0 + 32*i)
     const int c4 = tid & 7, row0 = tid >> 3;
     int iy0[AR], ix0[AR];
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int oy, ox;
-        pixel_of(row0 + 32 * i, oy, ox);
+        tm.pixel(row0 + 32 * i, oy, ox);
         iy0[i] = oy * d.stride - d.pad;
         ix0[i] = ox * d.stride - d.pad;
     }
@@ -103,12 +344,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             f32x4 v = a_st[i];
-            if (has_gn) {
-                if (a_valid & (1u << i)) {
-                    v = v * gsc + gsh;
-                    if (d.gn_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                }
-            }
+            if (has_gn && (a_valid & (1u << i))) v = gn_act(v, gsc, gsh, d.gn_silu);
             *reinterpret_cast<f32x4*>(&As[(row0 + 32 * i) * LDT + c4 * 4]) = v;
         }
 #pragma unroll
@@ -124,74 +360,117 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int n_iter = (p.Cin / KC) * p.ntaps;
+    const int nchunks = p.Cin / KC;
+    const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
+    const int it_begin = c_begin * p.ntaps, it_end = c_end * p.ntaps;
     const int frag_off = (lane & 31) * LDT + (lane >> 5) * 4;
     const float* a_frag = As + (wm * MT * 32) * LDT + frag_off;
     const float* b_frag = Bs + (wn * NT * 32) * LDT + frag_off;
 
-    prefetch(0);
-    for (int it = 0; it < n_iter; ++it) {
+    if (it_begin < it_end) prefetch(it_begin);
+    for (int it = it_begin; it < it_end; ++it) {
         __syncthreads();           // all waves finished reading the previous tile
         stage_to_lds();
         __syncthreads();
-        if (it + 1 < n_iter) prefetch(it + 1);
-#pragma unroll
-        for (int kk = 0; kk < KC / 8; ++kk) {
-            f32x4 a[MT], b[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDT + kk * 8);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
-        }
+        if (it + 1 < it_end) prefetch(it + 1);
+        mfma_tile_step<MT, NT>(a_frag, b_frag, acc);
     }
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, slice, acc);
+}
 
-    // ---- epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-    const int ncol = lane & 31, rsel = 4 * (lane >> 5);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
-        if (n >= d.Cout) continue;
-        float add = d.bias ? d.bias[n] : 0.f;
-        if (d.badd) add += d.badd[(size_t)img * d.badd_stride + n];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                int oy, ox;
-                pixel_of(row, oy, ox);
-                float v = acc[i][j][r] + add;
-                if (d.out_nchw) {
-                    d.out[((size_t)(img * d.Cout + n) * d.Ho + oy) * d.Wo + ox] = v;
-                } else {
-                    const size_t o = ((size_t)(img * d.Ho + oy) * d.Wo + ox) * d.Cout + n;
-                    if (d.res) v += d.res[o];
-                    d.out[o] = v;
-                }
+// =====================================================================================
+// split-K reduction + epilogue:  out = sum_s ws[s] + bias + badd + res   (fixed order)
+// =====================================================================================
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p, size_t total4) {
+    const ddnm_conv_desc& d = p.d;
+    const size_t slab4 = total4;
+    const int c4n = d.Cout >> 2;
+    const size_t hw = (size_t)d.Ho * d.Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(p.ws)[i];
+        for (int s = 1; s < p.ksplit; ++s) v = v + reinterpret_cast<const f32x4*>(p.ws)[i + s * slab4];
+        const int n = (int)(i % c4n) * 4;
+        const size_t pix = i / c4n;
+        const size_t b = pix / hw;
+        if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
+        if (d.badd) v = v + *reinterpret_cast<const f32x4*>(d.badd + b * d.badd_stride + n);
+        if (d.res) v = v + reinterpret_cast<const f32x4*>(d.res)[i];
+        reinterpret_cast<f32x4*>(d.out)[i] = v;
+    }
+}
+
+// =====================================================================================
+// host side: plan + launch
+// =====================================================================================
+struct ConvPlan {
+    int tile;       // 1: 128x128, 2: 64x64, 3: 128x32
+    int BM, BN;
+    bool halo;
+    int ksplit;
+    int TW, TW_log2, tiles_x;
+};
+
+static bool make_plan(const ddnm_conv_desc* d, ConvPlan* pl) {
+    const int HWo = d->Ho * d->Wo;
+    const int nchunks = (d->C0 + d->C1) / KC;
+    int tile = d->tile;
+    if (!tile) {
+        if (d->Cout <= 32) {
+            tile = (HWo % 128 == 0) ? 3 : 2;
+        } else {
+            tile = 2;
+            if (HWo % 128 == 0 && d->Cout % 128 == 0) {
+                // 128x128 whenever it can still occupy the chip (directly or through split-K)
+                const long tiles = (long)d->B * (HWo / 128) * (d->Cout / 128);
+                if (tiles * nchunks >= 256) tile = 1;
             }
         }
     }
-}
-
-static int pick_tile(const ddnm_conv_desc* d) {
-    if (d->tile) return d->tile;
-    const int HWo = d->Ho * d->Wo;
-    if (d->Cout <= 32) return (HWo % 128 == 0) ? 3 : 2;
-    // 128x128 when it still yields a full wave of workgroups, else 64x64
-    if (HWo % 128 == 0 && d->Cout % 128 == 0) {
-        const long tiles = (long)d->B * (HWo / 128) * (d->Cout / 128);
-        if (tiles >= 256) return 1;
+    pl->tile = tile;
+    pl->BM = tile == 2 ? 64 : 128;
+    pl->BN = tile == 1 ? 128 : (tile == 2 ? 64 : 32);
+    if (HWo % pl->BM) return false;
+    pl->halo = d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->Hin && d->Wo == d->Win;
+    // 2-D output tile: width 32 keeps the 32 rows of one MFMA tile on consecutive halo rows
+    // (conflict-free ds_read_b128); narrower images fall back to 16 / 8
+    int tw = 32;
+    while (tw > 8 && (d->Wo % tw || d->Ho % (pl->BM / tw) || pl->BM / tw < 1)) tw >>= 1;
+    const bool two_d = (d->Wo % tw == 0) && (d->Ho % (pl->BM / tw) == 0);
+    if (pl->halo && !two_d) pl->halo = false;
+    pl->TW = tw;
+    pl->TW_log2 = tw == 32 ? 5 : (tw == 16 ? 4 : 3);
+    pl->tiles_x = two_d ? d->Wo / tw : 0;
+    // split-K over channel chunks when the tile grid cannot fill the chip
+    const long tiles = (long)d->B * (HWo / pl->BM) * ((d->Cout + pl->BN - 1) / pl->BN);
+    int ks = 1;
+    if (!d->out_nchw && d->Cout % 4 == 0 && tiles < 192) {
+        ks = (int)((512 + tiles - 1) / tiles);
+        if (ks > nchunks) ks = nchunks;
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
     }
-    return 2;
+    pl->ksplit = ks;
+    return true;
 }
 
 extern "C" int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d) {
-    const int t = pick_tile(d);
-    return t == 1 ? 128 : (t == 2 ? 64 : 32);
+    ConvPlan pl;
+    if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
+    return pl.BN;
+}
+
+extern "C" int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d) {
+    ConvPlan pl;
+    if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout : 0;
+}
+
+template <int WM, int WN, int MT, int NT>
+static void launch_conv(bool halo, dim3 grid, hipStream_t s, const ConvArgs& p) {
+    if (halo)
+        hipLaunchKernelGGL((conv3x3_halo_f32_kernel<WM, WN, MT, NT>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_gather_f32_kernel<WM, WN, MT, NT>), grid, dim3(256), 0, s, p);
 }
 
 extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
@@ -202,35 +481,40 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->out_nchw && d->res) return DDNM_E_SHAPE;
+    ConvPlan pl;
+    if (!make_plan(d, &pl)) return DDNM_E_SHAPE;
+    if (pl.ksplit > 1) {
+        const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
+        if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;      // no scratch: run unsplit
+    }
     ConvArgs p;
     p.d = *d;
     p.Cin = d->C0 + d->C1;
     p.ntaps = d->ksize * d->ksize;
     p.Hs = d->ups ? d->Hin / 2 : d->Hin;
     p.Ws = d->ups ? d->Win / 2 : d->Win;
-    const int tile = pick_tile(d);
-    const int BM = tile == 2 ? 64 : 128, BN = tile == 1 ? 128 : (tile == 2 ? 64 : 32);
-    const int HWo = d->Ho * d->Wo;
-    if (HWo % BM) return DDNM_E_SHAPE;
-    p.m_tiles = d->B * (HWo / BM);
-    p.n_tiles = (d->Cout + BN - 1) / BN;
-    // 2-D output tiles (16 wide) keep the 3x3 halo of a tile compact in L2/L1
-    p.TW = 16;
-    const int TH = BM / p.TW;
-    if (d->Wo % p.TW == 0 && d->Ho % TH == 0) {
-        p.tiles_x = d->Wo / p.TW;
-    } else {
-        p.tiles_x = 0;
-    }
-    p.tiles_per_img = HWo / BM;
-    dim3 grid(p.m_tiles * p.n_tiles), block(256);
+    p.m_tiles = d->B * (d->Ho * d->Wo / pl.BM);
+    p.n_tiles = (d->Cout + pl.BN - 1) / pl.BN;
+    p.TW = pl.TW;
+    p.TW_log2 = pl.TW_log2;
+    p.tiles_x = pl.tiles_x;
+    p.ksplit = pl.ksplit;
+    p.ws = d->workspace;
+    dim3 grid(p.m_tiles * p.n_tiles, pl.ksplit);
     hipStream_t s = (hipStream_t)stream;
-    switch (tile) {
-        case 1: hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 2, 2>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_f32_kernel<2, 2, 1, 1>), grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL((conv_igemm_f32_kernel<4, 1, 1, 1>), grid, block, 0, s, p); break;
+    (void)hipGetLastError();      // drop stale errors of unrelated runtime calls
+    switch (pl.tile) {
+        case 1: launch_conv<2, 2, 2, 2>(pl.halo, grid, s, p); break;
+        case 2: launch_conv<2, 2, 1, 1>(pl.halo, grid, s, p); break;
+        case 3: launch_conv<4, 1, 1, 1>(pl.halo, grid, s, p); break;
         default: return DDNM_E_BADARG;
     }
     DDNM_LAUNCH_CHECK();
+    if (pl.ksplit > 1) {
+        const size_t total4 = (size_t)d->B * d->Ho * d->Wo * d->Cout / 4;
+        const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p, total4);
+        DDNM_LAUNCH_CHECK();
+    }
     return 0;
 }

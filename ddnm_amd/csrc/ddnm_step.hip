@@ -41,9 +41,8 @@ extern "C" int ddnm_step_x0_f32(const float* xt, const float* et, int64_t et_bst
     if (!xt || !et || !x0 || !s || B <= 0 || chw <= 0) return DDNM_E_BADARG;
     if ((chw & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * chw / 4;
-    hipLaunchKernelGGL(step_x0_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride, x0,
+    DDNM_LAUNCH(step_x0_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride, x0,
                        chw / 4, total4, *s);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -68,9 +67,8 @@ extern "C" int ddnm_step_combine_f32(const float* x0, const float* proj, const f
     if (!x0 || !proj || !noise || !et || !xt_next || !s || B <= 0 || chw <= 0) return DDNM_E_BADARG;
     if ((chw & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * chw / 4;
-    hipLaunchKernelGGL(step_combine_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, x0, proj, apy, noise,
+    DDNM_LAUNCH(step_combine_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, x0, proj, apy, noise,
                        et, et_bstride, xt_next, chw / 4, total4, *s);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -116,20 +114,29 @@ extern "C" int ddnm_step_sr_avgpool_f32(const float* xt, const float* et, int64_
     if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0) return DDNM_E_BADARG;
     if (r != 4 || (H & 3) || (W & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total = (int64_t)B * 3 * (H / 4) * (W / 4);
-    hipLaunchKernelGGL(step_sr4_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride, noise,
+    DDNM_LAUNCH(step_sr4_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride, noise,
                        y, x0, xt_next, H, W, total, *s);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
 // ---------------------------------------------------------------- fused: colorization
-__constant__ float kColorW[3] = {0.3333f, 0.3334f, 0.3333f};
+struct ColorW { float w[3]; float wp[3]; };
+
+// w = per-pixel measurement row (default (0.3333, 0.3334, 0.3333), svd_operators.py:632); wp = w/|w|^2
+static ColorW color_weights(const float* w3_host) {
+    ColorW c;
+    const float dflt[3] = {0.3333f, 0.3334f, 0.3333f};
+    for (int i = 0; i < 3; ++i) c.w[i] = w3_host ? w3_host[i] : dflt[i];
+    const float n2 = (c.w[0] * c.w[0] + c.w[1] * c.w[1]) + c.w[2] * c.w[2];
+    for (int i = 0; i < 3; ++i) c.wp[i] = c.w[i] / n2;
+    return c;
+}
 
 __global__ __launch_bounds__(256) void step_color_kernel(const float* __restrict__ xt, const float* __restrict__ et,
                                                          int64_t et_bstride, const float* __restrict__ noise,
                                                          const float* __restrict__ y, float* __restrict__ x0o,
                                                          float* __restrict__ xn, int64_t hw4, int64_t total4,
-                                                         ddnm_step_scalars s, float wp0, float wp1, float wp2) {
+                                                         ddnm_step_scalars s, ColorW cw) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / hw4, p = i - b * hw4;
         const int64_t base = (b * 3 * hw4 + p) * 4, ebase = b * et_bstride + p * 4;
@@ -139,35 +146,25 @@ __global__ __launch_bounds__(256) void step_color_kernel(const float* __restrict
             e[c] = ld4(et + ebase + c * hw4 * 4);
             x0[c] = x0_of(ld4(xt + base + c * hw4 * 4), e[c], s);
         }
-        const f32x4 gray = (x0[0] * kColorW[0] + x0[1] * kColorW[1]) + x0[2] * kColorW[2];
+        const f32x4 gray = (x0[0] * cw.w[0] + x0[1] * cw.w[1]) + x0[2] * cw.w[2];
         const f32x4 resid = (gray - ld4(y + i * 4)) * s.lambda;
-        const float wp[3] = {wp0, wp1, wp2};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (x0o) st4(x0o + base + c * hw4 * 4, x0[c]);
-            const f32x4 x0h = x0[c] - resid * wp[c];
+            const f32x4 x0h = x0[c] - resid * cw.wp[c];
             st4(xn + base + c * hw4 * 4, update_of(x0h, ld4(noise + base + c * hw4 * 4), e[c], s));
         }
     }
 }
 
-static void color_pinv_weights(float* wp) {
-    const float w[3] = {0.3333f, 0.3334f, 0.3333f};
-    const float n2 = (w[0] * w[0] + w[1] * w[1]) + w[2] * w[2];
-    for (int c = 0; c < 3; ++c) wp[c] = w[c] / n2;
-}
-
 extern "C" int ddnm_step_color_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                                    const float* y, float* x0, float* xt_next, int32_t B, int32_t HW,
-                                   const ddnm_step_scalars* s, void* stream) {
+                                   const float* w3_host, const ddnm_step_scalars* s, void* stream) {
     if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0 || HW <= 0) return DDNM_E_BADARG;
     if ((HW & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
-    float wp[3];
-    color_pinv_weights(wp);
     const int64_t total4 = (int64_t)B * HW / 4;
-    hipLaunchKernelGGL(step_color_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
-                       noise, y, x0, xt_next, (int64_t)HW / 4, total4, *s, wp[0], wp[1], wp[2]);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(step_color_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
+                       noise, y, x0, xt_next, (int64_t)HW / 4, total4, *s, color_weights(w3_host));
     return 0;
 }
 
@@ -204,9 +201,8 @@ extern "C" int ddnm_step_inpaint_f32(const float* xt, const float* et, int64_t e
     if (!xt || !et || !noise || !y || !rank || !xt_next || !s || B <= 0 || HW <= 0) return DDNM_E_BADARG;
     if ((HW & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * HW / 4;
-    hipLaunchKernelGGL(step_inpaint_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
+    DDNM_LAUNCH(step_inpaint_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
                        noise, y, rank, n_kept, x0, xt_next, (int64_t)HW / 4, total4, *s);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -232,9 +228,8 @@ extern "C" int ddnm_step_denoise_f32(const float* xt, const float* et, int64_t e
     if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0 || chw <= 0) return DDNM_E_BADARG;
     if ((chw & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * chw / 4;
-    hipLaunchKernelGGL(step_denoise_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
+    DDNM_LAUNCH(step_denoise_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
                        noise, y, x0, xt_next, chw / 4, total4, *s);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -249,9 +244,8 @@ extern "C" int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_n
                                 void* stream) {
     if (!x0 || !noise || !xt_next || n <= 0) return DDNM_E_BADARG;
     if (n & 3) return DDNM_E_SHAPE;
-    hipLaunchKernelGGL(renoise_kernel, GRID_1D(n / 4), dim3(256), 0, (hipStream_t)stream, x0, noise, xt_next, n / 4, a,
+    DDNM_LAUNCH(renoise_kernel, GRID_1D(n / 4), dim3(256), 0, (hipStream_t)stream, x0, noise, xt_next, n / 4, a,
                        b);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -277,8 +271,7 @@ extern "C" int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t
     if (!x || !y || BC <= 0 || r <= 0) return DDNM_E_BADARG;
     if (H % r || W % r) return DDNM_E_SHAPE;
     const int64_t total = (int64_t)BC * (H / r) * (W / r);
-    hipLaunchKernelGGL(avgpool_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, H, W, r, total);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(avgpool_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, H, W, r, total);
     return 0;
 }
 
@@ -298,48 +291,46 @@ extern "C" int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_
     if (!x || !y || BC <= 0 || r <= 0) return DDNM_E_BADARG;
     if (H % r || W % r) return DDNM_E_SHAPE;
     const int64_t total = (int64_t)BC * H * W;
-    hipLaunchKernelGGL(upsample_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, x, H, W, r, total);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(upsample_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, x, H, W, r, total);
     return 0;
 }
 
 __global__ __launch_bounds__(256) void color_A_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t HW,
-                                                      int64_t total) {
+                                                      int64_t total, ColorW cw) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / HW, p = i - b * HW;
         const float* s = x + b * 3 * HW + p;
-        y[i] = (s[0] * kColorW[0] + s[HW] * kColorW[1]) + s[2 * HW] * kColorW[2];
+        y[i] = (s[0] * cw.w[0] + s[HW] * cw.w[1]) + s[2 * HW] * cw.w[2];
     }
 }
 
-extern "C" int ddnm_op_color_A_f32(const float* x, float* y, int32_t B, int32_t HW, void* stream) {
+extern "C" int ddnm_op_color_A_f32(const float* x, float* y, int32_t B, int32_t HW, const float* w3_host,
+                                   void* stream) {
     if (!x || !y || B <= 0 || HW <= 0) return DDNM_E_BADARG;
     const int64_t total = (int64_t)B * HW;
-    hipLaunchKernelGGL(color_A_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, (int64_t)HW, total);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(color_A_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, (int64_t)HW, total,
+                       color_weights(w3_host));
     return 0;
 }
 
 __global__ __launch_bounds__(256) void color_pinv_kernel(const float* __restrict__ y, float* __restrict__ x, int64_t HW,
-                                                         int64_t total, float wp0, float wp1, float wp2) {
+                                                         int64_t total, ColorW cw) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / HW, p = i - b * HW;
         float* d = x + b * 3 * HW + p;
         const float v = y[i];
-        d[0] = v * wp0;
-        d[HW] = v * wp1;
-        d[2 * HW] = v * wp2;
+        d[0] = v * cw.wp[0];
+        d[HW] = v * cw.wp[1];
+        d[2 * HW] = v * cw.wp[2];
     }
 }
 
-extern "C" int ddnm_op_color_pinv_f32(const float* y, float* x, int32_t B, int32_t HW, void* stream) {
+extern "C" int ddnm_op_color_pinv_f32(const float* y, float* x, int32_t B, int32_t HW, const float* w3_host,
+                                      void* stream) {
     if (!x || !y || B <= 0 || HW <= 0) return DDNM_E_BADARG;
-    float wp[3];
-    color_pinv_weights(wp);
     const int64_t total = (int64_t)B * HW;
-    hipLaunchKernelGGL(color_pinv_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, x, (int64_t)HW, total,
-                       wp[0], wp[1], wp[2]);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(color_pinv_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, x, (int64_t)HW, total,
+                       color_weights(w3_host));
     return 0;
 }
 
@@ -362,9 +353,8 @@ extern "C" int ddnm_op_inpaint_A_f32(const float* x, const int32_t* rank, int32_
                                      int32_t HW, void* stream) {
     if (!x || !y || !rank || B <= 0 || HW <= 0) return DDNM_E_BADARG;
     const int64_t total = (int64_t)B * HW;
-    hipLaunchKernelGGL(inpaint_A_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, rank, n_kept, y,
+    DDNM_LAUNCH(inpaint_A_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, rank, n_kept, y,
                        (int64_t)HW, total);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -388,9 +378,8 @@ extern "C" int ddnm_op_inpaint_pinv_f32(const float* y, const int32_t* rank, int
                                         int32_t HW, void* stream) {
     if (!x || !y || !rank || B <= 0 || HW <= 0) return DDNM_E_BADARG;
     const int64_t total = (int64_t)B * HW;
-    hipLaunchKernelGGL(inpaint_pinv_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, rank, n_kept, x,
+    DDNM_LAUNCH(inpaint_pinv_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, y, rank, n_kept, x,
                        (int64_t)HW, total);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -427,7 +416,6 @@ extern "C" int ddnm_finalize_psnr_f32(const float* x, const float* x_orig, float
         hipError_t e = hipMemsetAsync(sse, 0, sizeof(double) * B, st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(finalize_psnr_kernel, dim3(64, B), dim3(256), 0, st, x, x_orig, img, sse, chw);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(finalize_psnr_kernel, dim3(64, B), dim3(256), 0, st, x, x_orig, img, sse, chw);
     return 0;
 }

@@ -83,12 +83,10 @@ extern "C" int ddnm_fwht2d_f32(const float* in, float* out, int32_t planes, int3
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)planes * n;
     const int rows_per_block = 4 * (64 / (n / 4));
-    hipLaunchKernelGGL(fwht_rows_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
+    DDNM_LAUNCH(fwht_rows_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
                        s, in, out, n, rows, 1.0f);
-    DDNM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fwht_cols_kernel<false>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
+    DDNM_LAUNCH(fwht_cols_kernel<false>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
                        out, nullptr, 1, out, n, 1.0f / (float)n);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -101,13 +99,10 @@ extern "C" int ddnm_fwht2d_masked_f32(const float* in, const float* mask, int32_
     const int rows_per_block = 4 * (64 / (n / 4));
     const dim3 grid_rows((unsigned)((rows + rows_per_block - 1) / rows_per_block));
     // H in (unnormalised rows), then cols-mask-cols with the forward 1/n, then rows with the inverse 1/n
-    hipLaunchKernelGGL(fwht_rows_kernel, grid_rows, dim3(256), 0, s, in, scratch, n, rows, 1.0f);
-    DDNM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fwht_cols_kernel<true>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
+    DDNM_LAUNCH(fwht_rows_kernel, grid_rows, dim3(256), 0, s, in, scratch, n, rows, 1.0f);
+    DDNM_LAUNCH(fwht_cols_kernel<true>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
                        scratch, mask, planes_mask, scratch, n, 1.0f / (float)n);
-    DDNM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fwht_rows_kernel, grid_rows, dim3(256), 0, s, scratch, out, n, rows, 1.0f / (float)n);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(fwht_rows_kernel, grid_rows, dim3(256), 0, s, scratch, out, n, rows, 1.0f / (float)n);
     return 0;
 }
 
@@ -129,9 +124,8 @@ extern "C" int ddnm_wh_gather_f32(const float* planes, const int32_t* perm, floa
         return DDNM_E_BADARG;
     const int64_t total = (int64_t)B * n_keep;
     const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(wh_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, planes, perm, y, C, (int64_t)N,
+    DDNM_LAUNCH(wh_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, planes, perm, y, C, (int64_t)N,
                        (int64_t)n_keep, total);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -153,8 +147,7 @@ extern "C" int ddnm_wh_scatter_f32(const float* y, const int32_t* perm, float* p
         return DDNM_E_BADARG;
     const int64_t total = (int64_t)B * C * N;
     const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(wh_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, perm, planes, C, (int64_t)N,
+    DDNM_LAUNCH(wh_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, perm, planes, C, (int64_t)N,
                        (int64_t)n_keep, total);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }

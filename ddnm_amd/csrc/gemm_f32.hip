@@ -136,20 +136,18 @@ extern "C" int ddnm_bgemm_f32(const ddnm_gemm_desc* d, void* stream) {
     if (d->M % 64 || d->N % 64 || d->K % KC || !aligned) {
         const int64_t total = (int64_t)d->M * d->N * d->batch;
         const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(bgemm_naive_kernel, dim3(grid), dim3(256), 0, s, *d);
-        DDNM_LAUNCH_CHECK();
+        DDNM_LAUNCH(bgemm_naive_kernel, dim3(grid), dim3(256), 0, s, *d);
         return 0;
     }
     const bool big = (d->M % 128 == 0) && (d->N % 128 == 0) &&
                      ((long)d->batch * (d->M / 128) * (d->N / 128) >= 256);
     if (big) {
         const int mt = d->M / 128, nt = d->N / 128;
-        hipLaunchKernelGGL((bgemm_f32_kernel<2, 2>), dim3(d->batch * mt * nt), dim3(256), 0, s, *d, mt, nt);
+        DDNM_LAUNCH((bgemm_f32_kernel<2, 2>), dim3(d->batch * mt * nt), dim3(256), 0, s, *d, mt, nt);
     } else {
         const int mt = d->M / 64, nt = d->N / 64;
-        hipLaunchKernelGGL((bgemm_f32_kernel<1, 1>), dim3(d->batch * mt * nt), dim3(256), 0, s, *d, mt, nt);
+        DDNM_LAUNCH((bgemm_f32_kernel<1, 1>), dim3(d->batch * mt * nt), dim3(256), 0, s, *d, mt, nt);
     }
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -190,8 +188,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, int64_t row
 extern "C" int ddnm_softmax_rows_f32(float* x, int64_t rows, int32_t n, int32_t ld, float scale, void* stream) {
     if (!x || rows <= 0 || n <= 0) return DDNM_E_BADARG;
     if (n > 64 * 32) return DDNM_E_SHAPE;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+    DDNM_LAUNCH(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
                        rows, n, ld, scale);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }

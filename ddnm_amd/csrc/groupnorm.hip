@@ -66,9 +66,8 @@ extern "C" int ddnm_gn_stats_f32(const float* src0, const float* src1, int32_t B
     const int C4 = C / 4, bd = gn_block_dim(C4);
     const int rows = bd / C4, pix = rows * GN_PIX_PER_THREAD;
     if (nchunk != (HW + pix - 1) / pix) return DDNM_E_BADARG;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), (hipStream_t)stream, src0,
+    DDNM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), (hipStream_t)stream, src0,
                        src1, HW, C0, C1, groups, partial, nchunk, pix);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -117,8 +116,7 @@ extern "C" int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const
                                     float* shift, void* stream) {
     if (!partial || !gamma || !beta || !scale || !shift || B <= 0 || nchunk <= 0) return DDNM_E_BADARG;
     if (groups <= 0 || groups > 64 || C % groups) return DDNM_E_SHAPE;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, gamma, beta,
+    DDNM_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, gamma, beta,
                        HW, C, groups, eps, scale, shift);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }

@@ -27,9 +27,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 extern "C" int ddnm_linear_f32(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t K,
                                int32_t N, int32_t silu_in, void* stream) {
     if (!x || !W || !y || B <= 0 || K <= 0 || N <= 0) return DDNM_E_BADARG;
-    hipLaunchKernelGGL(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, K, N,
+    DDNM_LAUNCH(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, K, N,
                        silu_in);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 
@@ -48,8 +47,7 @@ __global__ void temb_kernel(const float* __restrict__ t, const float* __restrict
 extern "C" int ddnm_timestep_embedding_f32(const float* t, const float* freq, float* emb, int32_t B, int32_t half,
                                            int32_t order, void* stream) {
     if (!t || !freq || !emb || B <= 0 || half <= 0) return DDNM_E_BADARG;
-    hipLaunchKernelGGL(temb_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, t, freq, emb, half, order);
-    DDNM_LAUNCH_CHECK();
+    DDNM_LAUNCH(temb_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, t, freq, emb, half, order);
     return 0;
 }
 
@@ -77,9 +75,8 @@ extern "C" int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B
     if (!src || !dst || B <= 0 || C <= 0 || HW <= 0 || Cpad < C || (Cpad & 3)) return DDNM_E_BADARG;
     const size_t total4 = (size_t)B * HW * (Cpad / 4);
     const unsigned grid = (unsigned)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, Cpad,
+    DDNM_LAUNCH(nchw_to_nhwc_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, HW, Cpad,
                        total4);
-    DDNM_LAUNCH_CHECK();
     return 0;
 }
 

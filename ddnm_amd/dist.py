@@ -1,0 +1,79 @@
+"""Multi-GPU driver pieces: one process per GPU, images sharded by index, one RCCL gather.
+
+The reference scales with `torch.nn.DataParallel` (guided_diffusion/diffusion.py:140,164), i.e. a
+parameter broadcast + scatter/gather inside EVERY model call.  Images of a batch are independent
+trajectories, so here each rank keeps its own replica of the packed weights,
+runs the whole reverse loop on its slice of the batch and of the noise tape, and the only
+communication is ONE `all_gather` of the restored images (786 KB per image) over xGMI at the end.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment (backend "nccl" == RCCL on ROCm)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    return rank, local_rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous slice [lo, hi) of `n_items` images owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(rank, world, *tensors):
+    """Slice every tensor / list-of-tensors (noise tape) along the image axis."""
+    out = []
+    for t in tensors:
+        if isinstance(t, (list, tuple)):
+            lo, hi = shard_range(t[0].shape[0], rank, world)
+            out.append([x[lo:hi] for x in t])
+        else:
+            lo, hi = shard_range(t.shape[0], rank, world)
+            out.append(t[lo:hi])
+    return out
+
+
+def gather_images(x_local, n_total=None):
+    """The path's single collective: all ranks receive the full restored batch, in image order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x_local
+    world = dist.get_world_size()
+    n_total = x_local.shape[0] * world if n_total is None else n_total
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    max_n = max(hi - lo for lo, hi in sizes)
+    pad = x_local
+    if x_local.shape[0] < max_n:     # all_gather needs equal shapes
+        pad = torch.cat([x_local, x_local.new_zeros(max_n - x_local.shape[0], *x_local.shape[1:])], 0)
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+
+
+def reduce_sum(value, device):
+    """Scalar sum over ranks (PSNR accumulation, diffusion.py:602)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.item()
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -129,32 +129,36 @@ class SuperResolution(A_functions):
 
 
 class Colorization(A_functions):
-    def __init__(self, img_dim, device):
+    def __init__(self, img_dim, device, weights=None):
+        """`weights`: per-pixel measurement row; None = (0.3333, 0.3334, 0.3333) (svd_operators.py:632).
+        The simplified path passes (1/3, 1/3, 1/3) (guided_diffusion/diffusion.py:33-42)."""
         self.channels, self.img_dim, self.device = 3, img_dim, device
+        self._w = None if weights is None else (ctypes.c_float * 3)(*[float(v) for v in weights])
 
     def A(self, vec):
         x = _img(vec, 3, self.img_dim)
         B, HW = x.shape[0], self.img_dim ** 2
         y = torch.empty(B, HW, dtype=torch.float32, device=x.device)
-        check(_lib.lib().ddnm_op_color_A_f32(_p(x), _p(y), B, HW, ops._stream()), "ddnm_op_color_A_f32")
+        check(_lib.lib().ddnm_op_color_A_f32(_p(x), _p(y), B, HW, self._w, ops._stream()), "ddnm_op_color_A_f32")
         return y
 
     def A_pinv(self, vec):
         B, HW = vec.shape[0], self.img_dim ** 2
         y = vec.reshape(B, -1).float().contiguous()
         x = torch.empty(B, 3 * HW, dtype=torch.float32, device=y.device)
-        check(_lib.lib().ddnm_op_color_pinv_f32(_p(y), _p(x), B, HW, ops._stream()), "ddnm_op_color_pinv_f32")
+        check(_lib.lib().ddnm_op_color_pinv_f32(_p(y), _p(x), B, HW, self._w, ops._stream()), "ddnm_op_color_pinv_f32")
         return x
 
     def singulars(self):
-        w = torch.tensor([0.3333, 0.3334, 0.3333])
+        w = torch.tensor([0.3333, 0.3334, 0.3333] if self._w is None else list(self._w))
         return torch.full((self.img_dim ** 2,), float((w * w).sum().sqrt()), device=self.device)
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         B = xt.shape[0]
         ep, es = ops._et_args(et)
         check(_lib.lib().ddnm_step_color_f32(_p(xt), ep, es, _p(noise), _p(y), _p(x0_out), _p(xt_next), B,
-                                             self.img_dim ** 2, ctypes.byref(s), ops._stream()), "ddnm_step_color_f32")
+                                             self.img_dim ** 2, self._w, ctypes.byref(s), ops._stream()),
+              "ddnm_step_color_f32")
 
 
 class Inpainting(A_functions):

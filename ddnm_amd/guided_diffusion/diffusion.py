@@ -1,0 +1,332 @@
+"""Runner of the DDNM CLI on MI355X: `Diffusion(args, config).sample(simplified)`.
+
+Same seam as the reference's `guided_diffusion/diffusion.py::Diffusion` (:79-610): it is built
+from the argparse namespace + YAML namespace of `main.py`, constructs the noise predictor and the
+degradation operator for `--deg`, forms `y = A(x_orig)`, draws `x_T`, runs the reverse loop and
+reports PSNR.  The hot path underneath is ours: `ddnm_amd.guided_diffusion.models.Model`,
+`ddnm_amd.functions.svd_operators.*`, `ddnm_amd.functions.svd_ddnm.ddnm_diffusion`.
+
+Deliberate differences at the boundary (not in the results):
+  * checkpoints are never downloaded (no network): `exp/logs/celeba/celeba_hq.ckpt` must exist,
+    or `DDNM_RANDOM_WEIGHTS=1` selects seeded random weights of the same architecture;
+  * images are read/written with PIL (torchvision is not required);
+  * multi-GPU is one process per GPU with the dataset sharded by index and one RCCL gather of the
+    PSNR sum (ddnm_amd.dist), not `torch.nn.DataParallel` (:140,164).
+"""
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from .. import dist as ddist
+from .. import ops
+from ..functions.svd_ddnm import _AlphaTable, ddnm_diffusion, get_schedule_jump
+from ..functions.svd_operators import (Colorization, Denoising, Inpainting, SuperResolution, build_operator)
+from .models import Model
+
+
+def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
+    """float64 schedules of diffusion.py:46-76."""
+    n = num_diffusion_timesteps
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, n, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(n, dtype=np.float64)
+    elif beta_schedule == "jsd":
+        betas = 1.0 / np.linspace(n, 1, n, dtype=np.float64)
+    elif beta_schedule == "sigmoid":
+        s = np.linspace(-6, 6, n)
+        betas = 1 / (np.exp(-s) + 1) * (beta_end - beta_start) + beta_start
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (n,)
+    return betas
+
+
+IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp")
+
+
+class ImageFolder(data.Dataset):
+    """torchvision.datasets.ImageFolder + Resize([S,S]) + ToTensor (datasets/__init__.py:144-150):
+    classes = sorted sub-directories, files sorted inside each."""
+
+    def __init__(self, root, image_size):
+        from PIL import Image  # noqa: F401
+        self.size = image_size
+        self.items = []
+        classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+        for ci, c in enumerate(classes):
+            for dirpath, _, files in sorted(os.walk(os.path.join(root, c))):
+                for f in sorted(files):
+                    if f.lower().endswith(IMG_EXT):
+                        self.items.append((os.path.join(dirpath, f), ci))
+        if not self.items:
+            raise FileNotFoundError(f"no images under {root}")
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        path, cls = self.items[i]
+        img = Image.open(path).convert("RGB").resize((self.size, self.size), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+        return x, cls
+
+
+class SyntheticImages(data.Dataset):
+    """Seeded U[0,1] images (BASELINE metric inputs; `--path_y synthetic:N`)."""
+
+    def __init__(self, n, image_size, seed):
+        self.n, self.size, self.seed = n, image_size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        return torch.rand(3, self.size, self.size, generator=g), 0
+
+
+def save_image(x, path):
+    """torchvision.utils.save_image for one [3,H,W] image in [0,1]."""
+    from PIL import Image
+    arr = x.detach().float().cpu().mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr).save(path)
+
+
+def data_transform(config, X):
+    """datasets/__init__.py:201-216 for the configs on the hot path (rescaled: 2x - 1)."""
+    if getattr(config.data, "uniform_dequantization", False) or getattr(config.data, "gaussian_dequantization", False):
+        raise NotImplementedError("dequantization transforms are training-time options")
+    if config.data.rescaled:
+        return 2 * X - 1.0
+    raise NotImplementedError("only rescaled data is on the DDNM hot path")
+
+
+class Diffusion(object):
+    def __init__(self, args, config, device=None):
+        self.args, self.config = args, config
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("ddnm_amd needs an MI355X: the hot path has no CPU fallback")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = device
+        self.model_var_type = config.model.var_type
+        betas = get_beta_schedule(beta_schedule=config.diffusion.beta_schedule, beta_start=config.diffusion.beta_start,
+                                  beta_end=config.diffusion.beta_end,
+                                  num_diffusion_timesteps=config.diffusion.num_diffusion_timesteps)
+        self.betas = torch.from_numpy(betas).float().to(self.device)
+        self.num_timesteps = self.betas.shape[0]
+
+    # ------------------------------------------------------------------ model construction
+    def _build_model(self):
+        cfg = self.config
+        if cfg.model.type == "simple":
+            if cfg.data.dataset != "CelebA_HQ":
+                raise ValueError("only the celeba_hq checkpoint family is wired for model.type=simple")
+            model = Model(cfg, device=self.device)
+            ckpt = os.path.join(self.args.exp, "logs/celeba/celeba_hq.ckpt")
+            if os.path.exists(ckpt):
+                model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+            elif os.environ.get("DDNM_RANDOM_WEIGHTS") == "1":
+                print(f"[ddnm_amd] {ckpt} not found; DDNM_RANDOM_WEIGHTS=1 -> seeded random weights")
+                model.load_state_dict(model.random_state_dict(self.args.seed))
+            else:
+                raise FileNotFoundError(f"{ckpt} not found (no network here: place the checkpoint there, or set "
+                                        "DDNM_RANDOM_WEIGHTS=1 for seeded random weights)")
+            return model
+        if cfg.model.type == "openai":
+            raise NotImplementedError("the ADM UNet (guided_diffusion/unet.py) engine is the next hot-path row; "
+                                      "this build covers model.type=simple (celeba_hq.yml)")
+        raise ValueError(cfg.model.type)
+
+    def sample(self, simplified):
+        model = self._build_model()
+        tt = self.config.time_travel
+        print(("Run Simplified DDNM, without SVD." if simplified else "Run SVD-based DDNM."),
+              f"{tt.T_sampling} sampling steps.", f"travel_length = {tt.travel_length},",
+              f"travel_repeat = {tt.travel_repeat}.", f"Task: {self.args.deg}.")
+        if simplified:
+            self.simplified_ddnm_plus(model, None)
+        else:
+            self.svd_based_ddnm_plus(model, None)
+
+    # ------------------------------------------------------------------ data
+    def _loader(self):
+        args, config = self.args, self.config
+        if str(args.path_y).startswith("synthetic"):
+            n = int(str(args.path_y).split(":")[1]) if ":" in str(args.path_y) else config.sampling.batch_size
+            ds = SyntheticImages(n, config.data.image_size, args.seed)
+        elif config.data.dataset in ("CelebA_HQ", "FFHQ"):
+            ds = ImageFolder(os.path.join(args.exp, "datasets", args.path_y), config.data.image_size)
+            # datasets/__init__.py:152-167: indices shuffled with numpy seed 2019, all of them are "test"
+            idx = list(range(len(ds)))
+            state = np.random.get_state()
+            np.random.seed(2019)
+            np.random.shuffle(idx)
+            np.random.set_state(state)
+            ds = data.Subset(ds, idx)
+        else:
+            raise NotImplementedError(f"dataset {config.data.dataset}: ImageNet front-end comes with the ADM UNet")
+        if args.subset_start >= 0 and args.subset_end > 0:
+            assert args.subset_end > args.subset_start
+            ds = data.Subset(ds, range(args.subset_start, args.subset_end))
+        else:
+            args.subset_start, args.subset_end = 0, len(ds)
+        print(f"Dataset has size {len(ds)}")
+
+        def seed_worker(worker_id):
+            s = args.seed % 2 ** 32
+            np.random.seed(s)
+            random.seed(s)
+
+        g = torch.Generator()
+        g.manual_seed(args.seed)
+        return data.DataLoader(ds, batch_size=config.sampling.batch_size, shuffle=True, num_workers=0,
+                               worker_init_fn=seed_worker, generator=g)
+
+    # ------------------------------------------------------------------ SVD path (diffusion.py:419-610)
+    def svd_based_ddnm_plus(self, model, cls_fn):
+        args, config = self.args, self.config
+        loader = self._loader()
+        A_funcs = build_operator(args.deg, args.deg_scale, config, self.device)
+        args.sigma_y = 2 * args.sigma_y          # scaling to [-1, 1] (:524)
+        sigma_y = args.sigma_y
+        if sigma_y != 0.0:
+            raise NotImplementedError("sigma_y > 0 (DDNM+, ddnm_plus_diffusion) is the next hot-path row")
+        rank, _, world = ddist.env_world()
+        print(f"Start from {args.subset_start}")
+        idx_so_far = args.subset_start
+        psnr_sum, n_done = 0.0, 0
+        os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
+        for bi, (x_orig, classes) in enumerate(loader):
+            if bi % world != rank:               # batches are dealt round-robin to the ranks
+                idx_so_far += x_orig.shape[0]
+                continue
+            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
+            y = A_funcs.A(x_orig)
+            b = y.shape[0]
+            if args.add_noise:
+                y = y + torch.randn_like(y) * sigma_y
+            Apy = A_funcs.A_pinv(y).view(b, config.data.channels, config.data.image_size, config.data.image_size)
+            if args.deg == "colorization":
+                Apy = y.view(b, 1, config.data.image_size, config.data.image_size).repeat(1, 3, 1, 1)
+            elif args.deg == "inpainting":
+                Apy = Apy + A_funcs.A_pinv(A_funcs.A(torch.ones_like(Apy))).reshape(*Apy.shape) - 1
+            for i in range(b):
+                save_image(ops.finalize_psnr(Apy[i:i + 1].contiguous())[0][0],
+                           os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far + i}.png"))
+                save_image(ops.finalize_psnr(x_orig[i:i + 1])[0][0],
+                           os.path.join(args.image_folder, f"Apy/orig_{idx_so_far + i}.png"))
+            x = torch.randn(b, config.data.channels, config.data.image_size, config.data.image_size,
+                            device=self.device)
+            with torch.no_grad():
+                xs, _ = ddnm_diffusion(x, model, self.betas, args.eta, A_funcs, y, cls_fn=cls_fn, classes=classes,
+                                       config=config)
+            img, psnr = ops.finalize_psnr(xs[0], x_orig)
+            for j in range(b):
+                save_image(img[j], os.path.join(args.image_folder, f"{idx_so_far + j}_{0}.png"))
+            psnr_sum += float(psnr.sum())
+            n_done += b
+            idx_so_far += b
+            print("PSNR: %.2f" % (psnr_sum / n_done))
+        psnr_sum, n_done = ddist.reduce_sum(psnr_sum, self.device), ddist.reduce_sum(n_done, self.device)
+        print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
+        print("Number of samples: %d" % n_done)
+        return psnr_sum / max(n_done, 1)
+
+    # ------------------------------------------------------------------ simplified path (diffusion.py:211-415)
+    def _simplified_operator(self):
+        args, config = self.args, self.config
+        d, dev = config.data.image_size, self.device
+        if args.deg == "colorization":
+            return Colorization(d, dev, weights=(1 / 3, 1 / 3, 1 / 3))          # color2gray / gray2color :33-42
+        if args.deg == "denoising":
+            return Denoising(config.data.channels, d, dev)
+        if args.deg == "sr_averagepooling":
+            return SuperResolution(config.data.channels, d, round(args.deg_scale), dev)   # AdaptiveAvgPool2d / MeanUpsample
+        if args.deg == "inpainting":
+            mask = torch.from_numpy(np.load("exp/inp_masks/mask.npy")).reshape(-1)      # A = Ap = z * mask
+            r = torch.nonzero(mask == 0).long().reshape(-1) * 3
+            return Inpainting(config.data.channels, d, torch.cat([r, r + 1, r + 2], 0), dev)
+        if args.deg in ("mask_color_sr", "diy"):
+            raise NotImplementedError("composed degradations are listed under 'next' (SURVEY.md section 8f rank 2)")
+        raise NotImplementedError("degradation type not supported")
+
+    def simplified_ddnm_plus(self, model, cls_fn):
+        args, config = self.args, self.config
+        loader = self._loader()
+        print("args.deg:", args.deg)
+        op = self._simplified_operator()
+        args.sigma_y = 2 * args.sigma_y
+        sigma_y = args.sigma_y
+        print(f"Start from {args.subset_start}")
+        idx_so_far = args.subset_start
+        psnr_sum, n_done = 0.0, 0
+        os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
+        for x_orig, classes in loader:
+            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
+            if config.sampling.batch_size != 1:
+                raise ValueError("please change the config file to set batch size as 1")
+            y = op.A(x_orig)
+            Apy = op.A_pinv(y).view(*x_orig.shape)
+            save_image(ops.finalize_psnr(Apy.contiguous())[0][0], os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far}.png"))
+            save_image(ops.finalize_psnr(x_orig)[0][0], os.path.join(args.image_folder, f"Apy/orig_{idx_so_far}.png"))
+            x = torch.randn(y.shape[0], config.data.channels, config.data.image_size, config.data.image_size,
+                            device=self.device)
+            x = simplified_loop(x, model, self.betas, args.eta, op, y, sigma_y, config)
+            img, psnr = ops.finalize_psnr(x, x_orig)
+            # the reference names the file with the stale loop variable j = -1 (:402); reproduced
+            save_image(img[0], os.path.join(args.image_folder, f"{idx_so_far + (-1)}_{0}.png"))
+            psnr_sum += float(psnr[0])
+            idx_so_far += y.shape[0]
+            n_done += y.shape[0]
+            print("PSNR: %.2f" % (psnr_sum / n_done))
+        print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
+        print("Number of samples: %d" % n_done)
+        return psnr_sum / max(n_done, 1)
+
+
+def simplified_loop(x, model, betas, eta, op, y, sigma_y, config, noise=None):
+    """The loop inlined in the reference at diffusion.py:333-397: Eq. 19 lambda_t / gamma_t with
+    sigma_t = sqrt(1 - alpha_bar'^2) (sic, :356) and the whole noise term scaled by gamma_t (:384)."""
+    tt = config.time_travel
+    skip = config.diffusion.num_diffusion_timesteps // tt.T_sampling
+    times = get_schedule_jump(tt.T_sampling, tt.travel_length, tt.travel_repeat)
+    alpha = _AlphaTable(betas)
+    n = x.shape[0]
+    y = y.reshape(n, -1).float().contiguous()
+    xt = x.float().contiguous()
+    x0_t = torch.empty_like(xt)
+    bufs = [torch.empty_like(xt), torch.empty_like(xt)]
+    with torch.no_grad():
+        for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
+            i, j = i * skip, j * skip
+            if j < 0:
+                j = -1
+            at_next = alpha(j)
+            out = bufs[k & 1]
+            nz = torch.randn_like(xt) if noise is None else noise[k]
+            if j < i:
+                at = alpha(i)
+                sigma_t = (1 - at_next ** 2).sqrt()
+                et = model(xt, torch.full((n,), float(i), device=xt.device))
+                if et.size(1) == 6:
+                    et = et[:, :3]
+                if sigma_t >= at_next * sigma_y:
+                    lambda_t = 1.0
+                    gamma_t = float((sigma_t ** 2 - (at_next * sigma_y) ** 2).sqrt())
+                else:
+                    lambda_t = float(sigma_t / (at_next * sigma_y))
+                    gamma_t = 0.0
+                s = ops.step_scalars(at, at_next, eta, lam=lambda_t, gamma=gamma_t)
+                op.ddnm_step(xt, et, nz, y, s, x0_t, out)
+            else:
+                ops.renoise(x0_t, nz, float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
+            xt = out
+    return xt

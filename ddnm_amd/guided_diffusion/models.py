@@ -124,13 +124,70 @@ class Model:
     def parameters(self):
         return iter(())
 
-    def state_dict_keys(self):
-        """Keys this engine consumes (== reference Model.state_dict().keys())."""
-        keys = ["temb.dense.0", "temb.dense.1", "conv_in"]
-        out = []
-        for k in keys:
-            out += [k + ".weight", k + ".bias"]
-        return out
+    def state_dict_shapes(self):
+        """name -> shape of every tensor `load_state_dict` consumes; equals the reference
+        `Model(config).state_dict()` (pinned in tests/test_host_logic.py against the golden key list)."""
+        s = OrderedDict()
+
+        def conv(n, co, ci, k):
+            s[n + ".weight"], s[n + ".bias"] = (co, ci, k, k), (co,)
+
+        def vec2(n, c):
+            s[n + ".weight"], s[n + ".bias"] = (c,), (c,)
+
+        def resblock(rb):
+            n = rb.name
+            vec2(n + ".norm1", rb.cin)
+            conv(n + ".conv1", rb.cout, rb.cin, 3)
+            s[n + ".temb_proj.weight"], s[n + ".temb_proj.bias"] = (rb.cout, self.temb_ch), (rb.cout,)
+            vec2(n + ".norm2", rb.cout)
+            conv(n + ".conv2", rb.cout, rb.cout, 3)
+            if rb.cin != rb.cout:
+                conv(n + ".nin_shortcut", rb.cout, rb.cin, 1)
+
+        def attn(a):
+            vec2(a.name + ".norm", a.c)
+            for p in ("q", "k", "v", "proj_out"):
+                conv(f"{a.name}.{p}", a.c, a.c, 1)
+
+        s["temb.dense.0.weight"], s["temb.dense.0.bias"] = (self.temb_ch, self.ch), (self.temb_ch,)
+        s["temb.dense.1.weight"], s["temb.dense.1.bias"] = (self.temb_ch, self.temb_ch), (self.temb_ch,)
+        conv("conv_in", self.ch, self.in_channels, 3)
+        for lvl, (blocks, attns, has_down, c) in enumerate(self.down):
+            for rb in blocks:
+                resblock(rb)
+            for a in attns:
+                attn(a)
+            if has_down:
+                conv(f"down.{lvl}.downsample.conv", c, c, 3)
+        resblock(self.mid[0]), attn(self.mid[1]), resblock(self.mid[2])
+        for lvl in range(self.num_resolutions):
+            blocks, attns, has_up, c = self.up[lvl]
+            for rb in blocks:
+                resblock(rb)
+            for a in attns:
+                attn(a)
+            if has_up:
+                conv(f"up.{lvl}.upsample.conv", c, c, 3)
+        vec2("norm_out", self.final_ch)
+        conv("conv_out", self.out_ch, self.final_ch, 3)
+        return s
+
+    def random_state_dict(self, seed=1234):
+        """Seeded random weights (no checkpoints exist offline): N(0, 1/fan_in) kernels, GN gamma near 1."""
+        g = torch.Generator().manual_seed(seed)
+        sd = OrderedDict()
+        for name, shape in self.state_dict_shapes().items():
+            if name.endswith(".weight") and len(shape) >= 2:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                sd[name] = torch.randn(shape, generator=g) * fan_in ** -0.5
+            elif name.endswith(".weight"):
+                sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            else:
+                sd[name] = 0.05 * torch.randn(shape, generator=g)
+        return sd
 
     def load_state_dict(self, sd, strict=True):
         dev = self.device

@@ -28,8 +28,47 @@ def _f32c(t, name):
     return t
 
 
+# ----------------------------------------------------------------------------- kernel timing hook
+class KernelTimer:
+    """Optional per-launch timing of the convolution kernel with HIP events on the launch stream
+    (used by bench.py for the roofline figure; off in normal operation)."""
+
+    def __init__(self):
+        self.records = []          # (variant, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for variant, flops, e0, e1 in self.records:
+            r = out.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            r["launches"] += 1
+            r["flops"] += flops
+            r["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
 # ----------------------------------------------------------------------------- convolution
 CONV_COUT_ALIGN = 128
+
+
+_conv_ws = {}
+
+
+def _conv_workspace(device, floats):
+    """Split-K scratch, one buffer per device, grown on demand (stream order makes reuse safe)."""
+    ws = _conv_ws.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(int(floats), dtype=torch.float32, device=device)
+        _conv_ws[device] = ws
+    return ws
 
 
 def pack_conv_weight(w, cin_pad=None):
@@ -66,7 +105,21 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
     d.badd_stride, d.tile = badd_stride, tile
-    check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+    need = _lib.lib().ddnm_conv2d_f32_workspace_floats(ctypes.byref(d))
+    if need > 0:
+        ws = _conv_workspace(src0.device, need)
+        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+    if _timer is None:
+        check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+    else:
+        tn = _lib.lib().ddnm_conv2d_f32_tile_n(ctypes.byref(d))
+        kind = "conv3x3_halo_f32" if (ksize == 3 and stride == 1) else "conv_gather_f32"
+        variant = kind + {128: "<128x128>", 64: "<64x64>", 32: "<128x32>"}[tn]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+        e1.record()
+        _timer.records.append((variant, 2.0 * B * Ho * Wo * cout * ksize * ksize * (C0 + C1), e0, e1))
     return out
 
 

@@ -68,11 +68,16 @@ typedef struct ddnm_conv_desc {
     int32_t out_nchw;
     int32_t badd_stride;
     int32_t tile;           /* 0 auto; 1: 128x128, 2: 64x64, 3: 128x32 (M x N per workgroup) */
+    float* workspace;       /* split-K scratch (may be NULL: the kernel then runs unsplit) */
+    int64_t workspace_floats;
 } ddnm_conv_desc;
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
 /* N-tile (32 or 64 or 128) the kernel will use for this desc: Cout_pad of the packed weight. */
 int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d);
+/* Scratch floats the auto plan wants for this desc (0: no split-K); low-resolution layers whose tile
+ * grid cannot fill 256 CUs split their channel chunks over several workgroups per tile. */
+int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
@@ -154,9 +159,11 @@ int ddnm_step_combine_f32(const float* x0, const float* proj, const float* apy, 
 int ddnm_step_sr_avgpool_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                              const float* y /* [B][3][H/r][W/r] */, float* x0, float* xt_next, int32_t B,
                              int32_t H, int32_t W, int32_t r, const ddnm_step_scalars* s, void* stream);
+/* w3_host: HOST pointer to the 3 per-pixel weights, NULL = (0.3333, 0.3334, 0.3333) of
+ * svd_operators.py:632; the simplified path uses (1/3, 1/3, 1/3) (diffusion.py:33-42). */
 int ddnm_step_color_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                         const float* y /* [B][H*W] */, float* x0, float* xt_next, int32_t B, int32_t HW,
-                        const ddnm_step_scalars* s, void* stream);
+                        const float* w3_host, const ddnm_step_scalars* s, void* stream);
 int ddnm_step_inpaint_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                           const float* y /* [B][3*n_kept], HWC order of kept pixels */,
                           const int32_t* rank /* [HW]: index of pixel among kept ones, -1 if missing */,
@@ -171,8 +178,8 @@ int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_next, int64_
 /* Stand-alone operator kernels (A and A^+ of functions/svd_operators.py, direct form). */
 int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
 int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
-int ddnm_op_color_A_f32(const float* x, float* y, int32_t B, int32_t HW, void* stream);
-int ddnm_op_color_pinv_f32(const float* y, float* x, int32_t B, int32_t HW, void* stream);
+int ddnm_op_color_A_f32(const float* x, float* y, int32_t B, int32_t HW, const float* w3_host, void* stream);
+int ddnm_op_color_pinv_f32(const float* y, float* x, int32_t B, int32_t HW, const float* w3_host, void* stream);
 int ddnm_op_inpaint_A_f32(const float* x, const int32_t* rank, int32_t n_kept, float* y, int32_t B, int32_t HW,
                           void* stream);
 int ddnm_op_inpaint_pinv_f32(const float* y, const int32_t* rank, int32_t n_kept, float* x, int32_t B,

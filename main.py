@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""DDNM command line on MI355X -- same flags and YAML configs as the reference's main.py.
+
+    python main.py --ni --config celeba_hq.yml --path_y celeba_hq --eta 0.85 \
+                   --deg sr_bicubic --deg_scale 4 --sigma_y 0. -i celeba_sr_bc_4
+
+Flag names, defaults and side effects follow the reference (main.py:22-147): the image folder is
+`<exp>/image_samples/<-i>`, `--ni` overwrites it without asking, seeds are set for torch / numpy /
+the device generator, and any exception inside the run is logged while the process still exits 0
+(main.py:164-170).  Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N
+main.py ...` (one process per GPU); without torchrun it is a single-GPU run.
+
+`--path_y synthetic:N` (ours) replaces the dataset by N seeded uniform-noise images.
+"""
+import argparse
+import logging
+import os
+import shutil
+import sys
+import traceback
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+FLAGS = [
+    # (names, kwargs) in the order of the reference parser
+    (("--config",), dict(type=str, required=True, help="Path to the config file")),
+    (("--seed",), dict(type=int, default=1234, help="Set different seeds for diverse results")),
+    (("--exp",), dict(type=str, default="exp", help="Path for saving running related data.")),
+    (("--deg",), dict(type=str, required=True, help="Degradation")),
+    (("--path_y",), dict(type=str, required=True, help="Path of the test dataset.")),
+    (("--sigma_y",), dict(type=float, default=0.0, help="sigma_y")),
+    (("--eta",), dict(type=float, default=0.85, help="Eta")),
+    (("--simplified",), dict(action="store_true", help="Use simplified DDNM, without SVD")),
+    (("-i", "--image_folder"), dict(type=str, default="images", help="The folder name of samples")),
+    (("--deg_scale",), dict(type=float, default=0.0, help="deg_scale")),
+    (("--verbose",), dict(type=str, default="info", help="Verbose level: info | debug | warning | critical")),
+    (("--ni",), dict(action="store_true", help="No interaction. Suitable for Slurm Job launcher")),
+    (("--subset_start",), dict(type=int, default=-1)),
+    (("--subset_end",), dict(type=int, default=-1)),
+    (("-n", "--noise_type"), dict(type=str, default="gaussian", help="gaussian | 3d_gaussian | poisson | speckle")),
+    (("--add_noise",), dict(action="store_true")),
+]
+
+
+def to_namespace(tree):
+    ns = argparse.Namespace()
+    for key, val in tree.items():
+        setattr(ns, key, to_namespace(val) if isinstance(val, dict) else val)
+    return ns
+
+
+def parse_args_and_config(argv=None):
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for names, kw in FLAGS:
+        parser.add_argument(*names, **kw)
+    args = parser.parse_args(argv)
+
+    cfg_path = args.config if os.path.isabs(args.config) else os.path.join("configs", args.config)
+    if not os.path.exists(cfg_path):
+        cfg_path = os.path.join(HERE, "configs", args.config)
+    with open(cfg_path, "r") as f:
+        config = to_namespace(yaml.safe_load(f))
+
+    level = getattr(logging, args.verbose.upper(), None)
+    if not isinstance(level, int):
+        raise ValueError("level {} not supported".format(args.verbose))
+    handler = logging.StreamHandler()
+    handler.setFormatter(logging.Formatter("%(levelname)s - %(filename)s - %(asctime)s - %(message)s"))
+    root = logging.getLogger()
+    root.addHandler(handler)
+    root.setLevel(level)
+
+    rank = int(os.environ.get("RANK", 0))
+    os.makedirs(os.path.join(args.exp, "image_samples"), exist_ok=True)
+    args.image_folder = os.path.join(args.exp, "image_samples", args.image_folder)
+    if rank == 0:
+        if os.path.exists(args.image_folder):
+            overwrite = args.ni
+            if not overwrite:
+                answer = input(f"Image folder {args.image_folder} already exists. Overwrite? (Y/N)")
+                overwrite = answer.upper() == "Y"
+            if not overwrite:
+                print("Output image folder exists. Program halted.")
+                sys.exit(0)
+            shutil.rmtree(args.image_folder)
+        os.makedirs(args.image_folder)
+
+    device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    logging.info("Using device: {}".format(device))
+    config.device = device
+
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(args.seed)
+    return args, config
+
+
+def main(argv=None):
+    args, config = parse_args_and_config(argv)
+    try:
+        from ddnm_amd import dist as ddist
+        from ddnm_amd.guided_diffusion.diffusion import Diffusion
+        ddist.init()
+        ddist.barrier()          # rank 0 has (re)created the image folder
+        runner = Diffusion(args, config)
+        runner.sample(args.simplified)
+    except Exception:
+        logging.error(traceback.format_exc())
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

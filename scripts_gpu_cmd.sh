@@ -1,0 +1,3 @@
+cd /root/repo
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -8
+python __graft_entry__.py smoke 2>&1 | tail -2

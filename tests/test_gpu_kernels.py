@@ -37,7 +37,11 @@ CONV_CASES = [
     (2, 128, 128, 32, 3, 2, 0),    # Downsample: pad (0,1,0,1), stride 2
     (1, 32, 128, 32, 3, 1, 0),     # conv_in (image staged to 32 channels)
     (2, 128, 3, 32, 3, 1, 0),      # conv_out, tile 128x32
-    (8, 512, 512, 8, 3, 1, 0),     # 8x8 level: M tile = one image
+    (8, 512, 512, 8, 3, 1, 0),     # 8x8 level: M tile = one image, split-K
+    (2, 512, 512, 16, 3, 1, 0),    # split-K with the 128x128 tile
+    (1, 256, 256, 32, 3, 1, 0),    # TW = 32 halo
+    (1, 128, 128, 64, 3, 1, 1),
+    (2, 256, 512, 8, 1, 1, 0),     # 1x1 on the gather kernel with split-K
 ]
 
 

@@ -47,16 +47,20 @@ def test_forward_matches_oracle(hip, kind, batch):
     assert rel(e, ref) < FWD_TOL
 
 
-def test_forward_batch_independence(hip):
-    """Images of a batch are independent trajectories: B=4 == 4 x B=1, bitwise."""
+def test_forward_batch_independence_and_determinism(hip):
+    """Images of a batch are independent trajectories: B=4 == 4 x B=1 up to fp32
+    summation order (the split-K plan of the low-resolution layers depends on the launch's batch size),
+    and a repeated launch of the same shape is bit-for-bit reproducible (no atomics anywhere)."""
     from oracle import cases
     cfg, sd = cases.celeba_net("small")
     x, t = cases.forward_inputs(cfg, 4)
     eng = build_engine(cfg, sd)
     full = eng(x.cuda(), t.cuda()).cpu()
+    again = eng(x.cuda(), t.cuda()).cpu()
+    assert torch.equal(full, again)
     for i in range(4):
         one = eng(x[i:i + 1].cuda(), t[i:i + 1].cuda()).cpu()
-        assert torch.equal(one, full[i:i + 1])
+        assert rel(one, full[i:i + 1]) < 2e-6
 
 
 def test_model_requires_weights_and_gpu(hip):
