@@ -1,0 +1,76 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/ddnm_hip.h declares; the ctypes prototypes cover exactly that set; struct layouts
+match the header.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ddnm_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddnm_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ddnm_amd import _lib, build
+    build.build()                      # hipcc cross-compiles for gfx950 without a GPU
+    return _lib.lib()
+
+
+def test_header_symbols_are_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ddnm_hip.h but not exported"
+
+
+def test_prototypes_match_header():
+    from ddnm_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == declared_symbols()
+
+
+def test_version_and_error_strings(lib):
+    assert lib.ddnm_version() == 1
+    assert b"shape" in lib.ddnm_error_string(-2)
+    assert b"bad argument" in lib.ddnm_error_string(-1)
+    assert lib.ddnm_error_string(0) == b"success"
+
+
+def test_struct_layouts_match_header():
+    from ddnm_amd._lib import ConvDesc, GemmDesc, StepScalars
+    # 9 pointers + 16 int32 + pointer + int64 (8-byte aligned)
+    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8
+    assert ConvDesc.workspace.offset == 9 * 8 + 16 * 4
+    assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4
+    assert ctypes.sizeof(StepScalars) == 24
+    src = open(HEADER).read()
+    conv = src[src.index("typedef struct ddnm_conv_desc"):src.index("} ddnm_conv_desc;")]
+    fields = re.findall(r"\b(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*([A-Za-z0-9_, ]+);", conv)
+    names = [n.strip() for grp in fields for n in grp.split(",")]
+    assert names == [f[0] for f in ConvDesc._fields_]
+
+
+def test_argument_validation_without_gpu(lib):
+    """Entry points reject bad descriptors before touching the device."""
+    from ddnm_amd._lib import ConvDesc, GemmDesc
+    d = ConvDesc()
+    assert lib.ddnm_conv2d_f32(ctypes.byref(d), None) == -1
+    g = GemmDesc()
+    assert lib.ddnm_bgemm_f32(ctypes.byref(g), None) == -1
+    assert lib.ddnm_gn_nchunk(256 * 256, 128) == 128
+    assert lib.ddnm_gn_nchunk(64, 1024) == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ddnm_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.DDNMHipError):
+        _lib.lib()
