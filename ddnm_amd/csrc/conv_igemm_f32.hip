@@ -81,7 +81,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
     const int wm = wave / WN, wn = wave % WN;
     const int ncol = lane & 31, rsel = 4 * (lane >> 5);
     const bool partial = p.ksplit > 1;
-    float* ws = partial ? p.ws + (size_t)slice * d.B * d.Ho * d.Wo * d.Cout : nullptr;
+    float* __restrict__ ws = partial ? p.ws + (size_t)slice * d.B * d.Ho * d.Wo * d.Cout : nullptr;
+    const float* __restrict__ res = d.res;
+    float* __restrict__ out = d.out;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
@@ -93,21 +95,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            size_t o[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
                 int oy, ox;
                 tm.pixel(row, oy, ox);
-                float v = acc[i][j][r] + add;
-                const size_t o = ((size_t)(tm.img * d.Ho + oy) * d.Wo + ox) * d.Cout + n;
-                if (partial) {
-                    ws[o] = v;
-                } else if (d.out_nchw) {
-                    d.out[((size_t)(tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox] = v;
-                } else {
-                    if (d.res) v += d.res[o];
-                    d.out[o] = v;
-                }
+                o[r] = d.out_nchw && !partial ? ((size_t)(tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox
+                                              : ((size_t)(tm.img * d.Ho + oy) * d.Wo + ox) * d.Cout + n;
+            }
+            // all 16 residual loads of this 32x32 tile are issued before the first store (a
+            // load -> add -> store chain per element would serialise 16 HBM round trips)
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = (res && !partial) ? res[o[r]] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][j][r] + add + rv[r];
+                if (partial) ws[o[r]] = v;
+                else out[o[r]] = v;
             }
         }
     }
@@ -144,8 +150,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
     constexpr int MAXH = BM == 128 ? 204 : 136;          // (TH+2)*(TW+2) for TW in {8,16,32}
     constexpr int HR = (MAXH + 31) / 32;                 // halo rows staged per thread
     constexpr int BR = BN / 32;
+#ifndef DDNM_HALO_SINGLE_BUFFER
+    constexpr int NBUF = 2;        // weight tile double-buffered: one barrier per tap
+#else
+    constexpr int NBUF = 1;
+#endif
     __shared__ __attribute__((aligned(16))) float Hs[MAXH * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDT];
+#ifdef DDNM_PROBE_LDS_PAD
+    __shared__ float lds_pad[DDNM_PROBE_LDS_PAD];
+    if (p.Cin < 0) lds_pad[threadIdx.x] = 0.f;
+#endif
 
     const ddnm_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,9 +230,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
             }
         }
     };
-    auto stage_b = [&]() {
+    auto stage_b = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&Bs[(prow + 32 * i) * LDT + c4 * 4]) = b_st[i];
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDT + (prow + 32 * i) * LDT + c4 * 4]) = b_st[i];
     };
 
     f32x16 acc[MT][NT];
@@ -238,6 +254,56 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
     }
     const float* b_frag = Bs + (wn * NT * 32) * LDT + (lane & 31) * LDT + (lane >> 5) * 4;
 
+    auto mfma_tap = [&](int tap, int buf) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int tap_off = (ky * HWd + kx) * LDT;
+        const float* bf = b_frag + buf * BN * LDT;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off + kk * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(bf + j * 32 * LDT + kk * 8);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
+        }
+    };
+
+#ifndef DDNM_HALO_SINGLE_BUFFER
+    // ---- weight tile double-buffered: per tap  [write B(s+1) -> other buffer | issue loads B(s+2) |
+    //      MFMA(s) | barrier];  the halo is re-staged between two barriers at every chunk boundary.
+    if (c_begin < c_end) {
+        prefetch_halo(c_begin);
+        prefetch_b(c_begin, 0);
+        stage_halo();
+        stage_b(0);
+        prefetch_b(c_begin, 1);
+        __syncthreads();
+        int cur = 0;
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const bool last_tap = tap == 8, more = chunk + 1 < c_end;
+                if (!last_tap || more) {
+                    stage_b(cur ^ 1);                       // B(s+1) (its loads flew during the previous MFMAs)
+                    // loads for B(s+2)
+                    if (tap < 7) prefetch_b(chunk, tap + 2);
+                    else if (tap == 7) { if (more) { prefetch_b(chunk + 1, 0); prefetch_halo(chunk + 1); } }
+                    else if (more) prefetch_b(chunk + 1, 1);
+                }
+                mfma_tap(tap, cur);
+                __syncthreads();
+                if (last_tap && more) {                     // chunk boundary: every wave is done with Hs
+                    stage_halo();
+                    __syncthreads();
+                }
+                cur ^= 1;
+            }
+        }
+    }
+#else
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         prefetch_b(c_begin, 0);
@@ -246,7 +312,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         for (int tap = 0; tap < 9; ++tap) {
             __syncthreads();                 // previous MFMAs finished reading Bs (and Hs when tap == 0)
             if (tap == 0) stage_halo();
-            stage_b();
+            stage_b(0);
             __syncthreads();
             // loads for the next step fly while this step's MFMAs run
             if (tap < 8) {
@@ -255,22 +321,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
                 prefetch_b(chunk + 1, 0);
                 prefetch_halo(chunk + 1);
             }
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int tap_off = (ky * HWd + kx) * LDT;
-#pragma unroll
-            for (int kk = 0; kk < KC / 8; ++kk) {
-                f32x4 a[MT], b[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off + kk * 8);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDT + kk * 8);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
-            }
+            mfma_tap(tap, 0);
         }
     }
+#endif
     conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, slice, acc);
 }
 

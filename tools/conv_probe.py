@@ -20,14 +20,17 @@ CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out")
 
 VARIANTS = {
-    "base": [],
-    "no_gn": ["-DDDNM_PROBE_NO_GN"],
+    "dbuf": [],
+    "single": ["-DDDNM_HALO_SINGLE_BUFFER"],
 }
 
 # (name, B, C0, C1, Cout, H (input, pre-upsample), k, stride, ups, gn, res, tile)
 SHAPES = [
+    ("warmup", 8, 128, 0, 128, 256, 3, 1, 0, 1, 1, 0),
     ("c128_128_256_gn_res", 8, 128, 0, 128, 256, 3, 1, 0, 1, 1, 0),
     ("c128_128_256_plain", 8, 128, 0, 128, 256, 3, 1, 0, 0, 0, 0),
+    ("c128_128_256_gn_only", 8, 128, 0, 128, 256, 3, 1, 0, 1, 0, 0),
+    ("c128_128_256_res_only", 8, 128, 0, 128, 256, 3, 1, 0, 0, 1, 0),
     ("c256cat_128_256_gn", 8, 128, 128, 128, 256, 3, 1, 0, 1, 0, 0),
     ("c256cat_128_256_1x1", 8, 128, 128, 128, 256, 1, 1, 0, 0, 0, 0),
     ("c128_128_128_gn_res", 8, 128, 0, 128, 128, 3, 1, 0, 1, 1, 0),
@@ -89,7 +92,7 @@ def main():
                 assert rc == 0, rc
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 10
+            reps = 20
             e0.record()
             for _ in range(reps):
                 lib.ddnm_conv2d_f32(ctypes.byref(d), stream)
