@@ -25,6 +25,7 @@ class ConvDesc(Structure):
         ("ups", c_int32), ("gn_silu", c_int32), ("out_nchw", c_int32),
         ("badd_stride", c_int32), ("tile", c_int32),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
+        ("res_ups", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -56,12 +57,15 @@ PROTOTYPES = {
                                     c_int32, c_void_p]),
     "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),
     "ddnm_gn_finalize_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
-                                       c_float, c_void_p, c_void_p, c_void_p]),
+                                       c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "ddnm_bgemm_f32": (c_int32, [POINTER(GemmDesc), c_void_p]),
     "ddnm_softmax_rows_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "ddnm_linear_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                   c_void_p]),
     "ddnm_timestep_embedding_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_avgpool2_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                         c_int32, c_void_p]),
+    "ddnm_embedding_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ddnm_nchw_to_nhwc_pad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_step_x0_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, POINTER(StepScalars),
                                    c_void_p]),

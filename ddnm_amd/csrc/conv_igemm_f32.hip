@@ -107,8 +107,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
             // all 16 residual loads of this 32x32 tile are issued before the first store (a
             // load -> add -> store chain per element would serialise 16 HBM round trips)
             float rv[16];
+            if (res && !partial && d.res_ups) {      // residual read through a nearest x2 upsample
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rv[r] = (res && !partial) ? res[o[r]] : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                    int oy, ox;
+                    tm.pixel(row, oy, ox);
+                    rv[r] = res[((size_t)(tm.img * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) * d.Cout + n];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = (res && !partial) ? res[o[r]] : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[i][j][r] + add + rv[r];
@@ -448,7 +458,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
         const size_t b = pix / hw;
         if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
         if (d.badd) v = v + *reinterpret_cast<const f32x4*>(d.badd + b * d.badd_stride + n);
-        if (d.res) v = v + reinterpret_cast<const f32x4*>(d.res)[i];
+        if (d.res) {
+            if (d.res_ups) {
+                const size_t p2 = pix - b * hw;
+                const size_t oy = p2 / d.Wo, ox = p2 - oy * d.Wo;
+                v = v + *reinterpret_cast<const f32x4*>(d.res + ((b * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) * d.Cout + n);
+            } else {
+                v = v + reinterpret_cast<const f32x4*>(d.res)[i];
+            }
+        }
         reinterpret_cast<f32x4*>(d.out)[i] = v;
     }
 }
@@ -535,6 +553,7 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->out_nchw && d->res) return DDNM_E_SHAPE;
+    if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     ConvPlan pl;
     if (!make_plan(d, &pl)) return DDNM_E_SHAPE;
     if (pl.ksplit > 1) {

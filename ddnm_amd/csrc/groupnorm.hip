@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int HW, int C, int groups,
                                                           float eps, float* __restrict__ scale,
-                                                          float* __restrict__ shift) {
+                                                          float* __restrict__ shift,
+                                                          const float* __restrict__ film, int film_stride) {
     __shared__ double acc[64][4][2];
     __shared__ float mean_s[64], rstd_s[64];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -105,18 +106,24 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     const int cpg = C / groups;
     for (int c = tid; c < C; c += 256) {
         const int gg = c / cpg;
-        const float sc = rstd_s[gg] * gamma[c];
+        float sc = rstd_s[gg] * gamma[c];
+        float sh = beta[c] - mean_s[gg] * sc;
+        if (film) {   // FiLM: GN(x)*(1+s)+t  (guided_diffusion/unet.py:248-251), row = [s(0..C) | t(0..C)]
+            const float s1 = 1.0f + film[(size_t)b * film_stride + c];
+            sc = sc * s1;
+            sh = sh * s1 + film[(size_t)b * film_stride + C + c];
+        }
         scale[(size_t)b * C + c] = sc;
-        shift[(size_t)b * C + c] = beta[c] - mean_s[gg] * sc;
+        shift[(size_t)b * C + c] = sh;
     }
 }
 
 extern "C" int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gamma, const float* beta,
                                     int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, float* scale,
-                                    float* shift, void* stream) {
+                                    float* shift, const float* film, int32_t film_stride, void* stream) {
     if (!partial || !gamma || !beta || !scale || !shift || B <= 0 || nchunk <= 0) return DDNM_E_BADARG;
     if (groups <= 0 || groups > 64 || C % groups) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, gamma, beta,
-                       HW, C, groups, eps, scale, shift);
+                       HW, C, groups, eps, scale, shift, film, film_stride);
     return 0;
 }

@@ -80,6 +80,60 @@ extern "C" int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B
     return 0;
 }
 
+// 2x2 average pooling of an NHWC tensor with an optional per-(sample, channel) affine + swish applied
+// to every input element first: out = mean_2x2(act(in)).  Replaces the `down=True` ResBlock halves
+// h = AvgPool2d(SiLU(GroupNorm(x))) and x = AvgPool2d(x)  (guided_diffusion/unet.py:133-140,237-242).
+__global__ __launch_bounds__(256) void avgpool2_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ sc,
+                                                            const float* __restrict__ sh, int silu,
+                                                            float* __restrict__ out, int Ho, int Wo, int C4,
+                                                            size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t r = i / C4;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const size_t b = r / Ho;
+        const f32x4* src = reinterpret_cast<const f32x4*>(in) + ((b * 2 * Ho + 2 * oy) * (size_t)(2 * Wo) + 2 * ox) * C4 + c4;
+        f32x4 v[4] = {src[0], src[C4], src[(size_t)2 * Wo * C4], src[(size_t)2 * Wo * C4 + C4]};
+        if (sc) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(sc)[b * C4 + c4], t = reinterpret_cast<const f32x4*>(sh)[b * C4 + c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = v[k] * a + t;
+                if (silu) { v[k].x = silu_f(v[k].x); v[k].y = silu_f(v[k].y); v[k].z = silu_f(v[k].z); v[k].w = silu_f(v[k].w); }
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = ((v[0] + v[1]) + (v[2] + v[3])) * 0.25f;
+    }
+}
+
+extern "C" int ddnm_avgpool2_nhwc_f32(const float* in, const float* gn_scale, const float* gn_shift, int32_t silu,
+                                      float* out, int32_t B, int32_t Ho, int32_t Wo, int32_t C, void* stream) {
+    if (!in || !out || B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (gn_scale && !gn_shift)) return DDNM_E_BADARG;
+    if (C & 3) return DDNM_E_SHAPE;
+    const size_t total4 = (size_t)B * Ho * Wo * (C / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    DDNM_LAUNCH(avgpool2_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, gn_scale, gn_shift, silu, out,
+                Ho, Wo, C / 4, total4);
+    return 0;
+}
+
+// emb[b][:] += table[idx[b]][:]   (nn.Embedding lookup of the class label, guided_diffusion/unet.py:651-653)
+__global__ void embedding_add_kernel(float* __restrict__ emb, const float* __restrict__ table,
+                                     const int64_t* __restrict__ idx, int D) {
+    const int b = blockIdx.x;
+    const float* row = table + (size_t)idx[b] * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) emb[(size_t)b * D + i] += row[i];
+}
+
+extern "C" int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, int32_t B, int32_t D,
+                                      void* stream) {
+    if (!emb || !table || !idx || B <= 0 || D <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(embedding_add_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, table, idx, D);
+    return 0;
+}
+
 extern "C" int ddnm_version(void) { return 1; }
 
 extern "C" const char* ddnm_error_string(int code) {

@@ -78,6 +78,42 @@ class ImageFolder(data.Dataset):
         return x, cls
 
 
+def center_crop_arr(pil_image, image_size=256):
+    """datasets/__init__.py:29-44 (from openai/guided-diffusion): box-downsample while >= 2x, bicubic to the
+    short side, centre crop."""
+    from PIL import Image
+    while min(*pil_image.size) >= 2 * image_size:
+        pil_image = pil_image.resize(tuple(x // 2 for x in pil_image.size), resample=Image.BOX)
+    scale = image_size / min(*pil_image.size)
+    pil_image = pil_image.resize(tuple(round(x * scale) for x in pil_image.size), resample=Image.BICUBIC)
+    arr = np.array(pil_image)
+    cy, cx = (arr.shape[0] - image_size) // 2, (arr.shape[1] - image_size) // 2
+    return arr[cy:cy + image_size, cx:cx + image_size]
+
+
+class ImageList(data.Dataset):
+    """datasets/imagenet_subset.py::ImageDataset with normalize=False: list file of '<name> <label>'."""
+
+    def __init__(self, root, list_file, image_size):
+        self.root, self.size = root, image_size
+        self.items = []
+        with open(list_file) as f:
+            for line in f:
+                parts = line.split()
+                if parts:
+                    self.items.append((parts[0], int(parts[1]) if len(parts) > 1 else 0))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        name, label = self.items[i]
+        arr = center_crop_arr(Image.open(os.path.join(self.root, name)).convert("RGB"), self.size)
+        x = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
+        return x, label
+
+
 class SyntheticImages(data.Dataset):
     """Seeded U[0,1] images (BASELINE metric inputs; `--path_y synthetic:N`)."""
 
@@ -141,8 +177,28 @@ class Diffusion(object):
                                         "DDNM_RANDOM_WEIGHTS=1 for seeded random weights)")
             return model
         if cfg.model.type == "openai":
-            raise NotImplementedError("the ADM UNet (guided_diffusion/unet.py) engine is the next hot-path row; "
-                                      "this build covers model.type=simple (celeba_hq.yml)")
+            from .unet import create_model
+            model = create_model(**vars(cfg.model))
+            model.device = self.device
+            if cfg.model.use_fp16:
+                model.convert_to_fp16()          # accepted; this build evaluates the ADM net in fp32
+            if cfg.model.class_cond:
+                ckpt = os.path.join(self.args.exp, "logs/imagenet/%dx%d_diffusion.pt" % (
+                    cfg.data.image_size, cfg.data.image_size))
+            else:
+                ckpt = os.path.join(self.args.exp, "logs/imagenet/256x256_diffusion_uncond.pt")
+            if os.path.exists(ckpt):
+                model.load_state_dict(torch.load(ckpt, map_location="cpu"))
+            elif os.environ.get("DDNM_RANDOM_WEIGHTS") == "1":
+                print(f"[ddnm_amd] {ckpt} not found; DDNM_RANDOM_WEIGHTS=1 -> seeded random weights")
+                model.load_state_dict(model.random_state_dict(self.args.seed))
+            else:
+                raise FileNotFoundError(f"{ckpt} not found (no network here: place the checkpoint there, or set "
+                                        "DDNM_RANDOM_WEIGHTS=1 for seeded random weights)")
+            if cfg.model.class_cond:
+                raise NotImplementedError("classifier guidance (cond_fn over EncoderUNetModel, diffusion.py:166-191) "
+                                          "is the next hot-path row (SURVEY.md section 8 a16)")
+            return model
         raise ValueError(cfg.model.type)
 
     def sample(self, simplified):
@@ -171,8 +227,12 @@ class Diffusion(object):
             np.random.shuffle(idx)
             np.random.set_state(state)
             ds = data.Subset(ds, idx)
+        elif config.data.dataset == "ImageNet":
+            # datasets/__init__.py:166-175: exp/imagenet_val_1k.txt lists "<file> <label>" under exp/datasets/imagenet/imagenet
+            ds = ImageList(os.path.join(args.exp, "datasets", "imagenet", "imagenet"),
+                           os.path.join(args.exp, "imagenet_val_1k.txt"), config.data.image_size)
         else:
-            raise NotImplementedError(f"dataset {config.data.dataset}: ImageNet front-end comes with the ADM UNet")
+            raise NotImplementedError(f"dataset {config.data.dataset}")
         if args.subset_start >= 0 and args.subset_end > 0:
             assert args.subset_end > args.subset_start
             ds = data.Subset(ds, range(args.subset_start, args.subset_end))

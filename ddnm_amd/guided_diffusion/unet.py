@@ -1,0 +1,330 @@
+"""MI355X engine for the ImageNet (ADM / guided-diffusion) noise predictor.
+
+Drop-in for the reference's `guided_diffusion/unet.py::UNetModel` (:396-664) as built by
+`script_util.create_model` (:130-185): `create_model(**vars(config.model))` here takes the same
+keyword arguments, the engine loads the public checkpoints' state-dict unchanged (566 keys;
+`label_emb.weight` when class-conditional) and is called as `model(x, t[, y]) -> [B, 6, R, R]`.
+
+Kernel mapping (ddnm_amd/csrc), activations NHWC fp32 in HBM:
+  * every 3x3 / 1x1 conv and Conv1d(k=1)  -> the MFMA implicit-GEMM kernels, with GroupNorm(+FiLM)
+    + SiLU, nearest x2, skip concat fused into the loader and bias / residual (through a nearest
+    x2 upsample for `up=True` blocks) into the epilogue;
+  * FiLM  GN(h)*(1+scale)+shift (:248-251)  -> folded into the per-(sample, channel) affine by
+    `gn_finalize` -- no extra pass over the tensor;
+  * `down=True` halves AvgPool2d(SiLU(GN(x))) / AvgPool2d(x) (:237-242) -> one HBM-bound kernel each;
+  * QKVAttentionLegacy (:339-354): heads are strided views of the fused qkv tensor
+    (channel = head*192 + {q,k,v}*64 + c), QK^T and PV as batched MFMA GEMMs, fp32 softmax;
+  * all `emb_layers` Linears -> ONE launch per step.
+
+Precision: this build evaluates the ADM net in fp32 on `v_mfma_f32_32x32x2_f32` (the reference's
+fp16 torso, fp16_util.py:15-22, is *less* precise); the fp16-storage MFMA variant is the next
+step for throughput.  `convert_to_fp16()` is accepted and ignored.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from .. import ops
+
+GN_EPS = 1e-5          # torch.nn.GroupNorm default, guided_diffusion/nn.py:93-100
+CIN_PAD = 32
+NUM_CLASSES = 1000
+
+
+def create_model(image_size, num_channels, num_res_blocks, channel_mult="", learn_sigma=False, class_cond=False,
+                 use_checkpoint=False, attention_resolutions="16", num_heads=1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, dropout=0, resblock_updown=False, use_fp16=False,
+                 use_new_attention_order=False, **kwargs):
+    """script_util.py:130-185 (extra YAML keys are swallowed by **kwargs like in the reference)."""
+    if channel_mult == "":
+        table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+        if image_size not in table:
+            raise ValueError(f"unsupported image size: {image_size}")
+        channel_mult = table[image_size]
+    else:
+        channel_mult = tuple(int(v) for v in channel_mult.split(","))
+    attention_ds = tuple(image_size // int(res) for res in attention_resolutions.split(","))
+    return UNetModel(image_size=image_size, in_channels=3, model_channels=num_channels,
+                     out_channels=(3 if not learn_sigma else 6), num_res_blocks=num_res_blocks,
+                     attention_resolutions=attention_ds, channel_mult=channel_mult,
+                     num_classes=(NUM_CLASSES if class_cond else None), num_heads=num_heads,
+                     num_head_channels=num_head_channels, use_scale_shift_norm=use_scale_shift_norm,
+                     resblock_updown=resblock_updown, use_new_attention_order=use_new_attention_order)
+
+
+class UNetModel:
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 channel_mult=(1, 2, 4, 8), num_classes=None, num_heads=1, num_head_channels=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False, device=None,
+                 **kwargs):
+        if use_new_attention_order:
+            raise NotImplementedError("use_new_attention_order=True is not used by the DDNM configs")
+        if not resblock_updown:
+            raise NotImplementedError("conv_resample Up/Downsample layers are not used by the DDNM configs")
+        if not use_scale_shift_norm:
+            raise NotImplementedError("use_scale_shift_norm=False is not used by the DDNM configs")
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.num_classes = out_channels, num_classes
+        self.num_heads, self.num_head_channels = num_heads, num_head_channels
+        self.time_embed_dim = 4 * model_channels
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        mc = model_channels
+        ch = int(channel_mult[0] * mc)
+        self.input_blocks = [[("conv", in_channels, ch)]]
+        chans = [ch]
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [("res", ch, int(mult * mc), "")]
+                ch = int(mult * mc)
+                if ds in attention_resolutions:
+                    layers.append(("attn", ch))
+                self.input_blocks.append(layers)
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append([("res", ch, ch, "down")])
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = [("res", ch, ch, ""), ("attn", ch), ("res", ch, ch, "")]
+        self.output_blocks = []
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [("res", ch + ich, int(mc * mult), "", ch)]       # last field: channels of `h` in the concat
+                ch = int(mc * mult)
+                if ds in attention_resolutions:
+                    layers.append(("attn", ch))
+                if level and i == num_res_blocks:
+                    layers.append(("res", ch, ch, "up"))
+                    ds //= 2
+                self.output_blocks.append(layers)
+        self.final_ch = ch
+        # FiLM projection layout: one slice [2*cout] per ResBlock, in execution order
+        self._res_names = []
+        off = 0
+        self._film_off = {}
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                if L[0] == "res":
+                    n = f"{prefix}.{j}"
+                    self._film_off[n] = off
+                    off += 2 * L[2]
+                    self._res_names.append((n, L))
+        self.film_total = off
+        self.max_ch = max(L[1] for _, L in self._res_names)
+        self.w = None
+        self._ws = None
+
+    def _walk(self):
+        for i, layers in enumerate(self.input_blocks):
+            yield f"input_blocks.{i}", layers
+        yield "middle_block", self.middle_block
+        for i, layers in enumerate(self.output_blocks):
+            yield f"output_blocks.{i}", layers
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def convert_to_fp16(self):
+        """Accepted for drop-in compatibility (diffusion.py:145-146); this build computes in fp32."""
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def state_dict_shapes(self):
+        s = OrderedDict()
+        ted, mc = self.time_embed_dim, self.model_channels
+        s["time_embed.0.weight"], s["time_embed.0.bias"] = (ted, mc), (ted,)
+        s["time_embed.2.weight"], s["time_embed.2.bias"] = (ted, ted), (ted,)
+        if self.num_classes is not None:
+            s["label_emb.weight"] = (self.num_classes, ted)
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if L[0] == "conv":
+                    s[n + ".weight"], s[n + ".bias"] = (L[2], L[1], 3, 3), (L[2],)
+                elif L[0] == "res":
+                    cin, cout = L[1], L[2]
+                    s[n + ".in_layers.0.weight"], s[n + ".in_layers.0.bias"] = (cin,), (cin,)
+                    s[n + ".in_layers.2.weight"], s[n + ".in_layers.2.bias"] = (cout, cin, 3, 3), (cout,)
+                    s[n + ".emb_layers.1.weight"], s[n + ".emb_layers.1.bias"] = (2 * cout, ted), (2 * cout,)
+                    s[n + ".out_layers.0.weight"], s[n + ".out_layers.0.bias"] = (cout,), (cout,)
+                    s[n + ".out_layers.3.weight"], s[n + ".out_layers.3.bias"] = (cout, cout, 3, 3), (cout,)
+                    if cin != cout:
+                        s[n + ".skip_connection.weight"], s[n + ".skip_connection.bias"] = (cout, cin, 1, 1), (cout,)
+                else:
+                    c = L[1]
+                    s[n + ".norm.weight"], s[n + ".norm.bias"] = (c,), (c,)
+                    s[n + ".qkv.weight"], s[n + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
+                    s[n + ".proj_out.weight"], s[n + ".proj_out.bias"] = (c, c, 1), (c,)
+        s["out.0.weight"], s["out.0.bias"] = (self.final_ch,), (self.final_ch,)
+        s["out.2.weight"], s["out.2.bias"] = (self.out_channels, self.final_ch, 3, 3), (self.out_channels,)
+        return s
+
+    def random_state_dict(self, seed=1234):
+        g = torch.Generator().manual_seed(seed)
+        sd = OrderedDict()
+        for name, shape in self.state_dict_shapes().items():
+            if name.endswith(".weight") and len(shape) >= 2:
+                fan_in = 1
+                for d in shape[1:]:
+                    fan_in *= d
+                sd[name] = torch.randn(shape, generator=g) * fan_in ** -0.5
+            elif name.endswith(".weight"):
+                sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+            else:
+                sd[name] = 0.05 * torch.randn(shape, generator=g)
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        dev = self.device
+        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731 (fp16 ckpts upcast)
+        w = {}
+        for k in ("time_embed.0", "time_embed.2"):
+            w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
+        if self.num_classes is not None:
+            w["label_emb.weight"] = g("label_emb.weight")
+        fw, fb = [], []
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if L[0] == "conv":
+                    w[n + ".weight"] = ops.pack_conv_weight(g(n + ".weight"), cin_pad=CIN_PAD)
+                    w[n + ".bias"] = g(n + ".bias")
+                elif L[0] == "res":
+                    for norm in ("in_layers.0", "out_layers.0"):
+                        w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
+                    for conv in ("in_layers.2", "out_layers.3"):
+                        w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(g(f"{n}.{conv}.weight"))
+                        w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
+                    fw.append(g(n + ".emb_layers.1.weight"))
+                    fb.append(g(n + ".emb_layers.1.bias"))
+                    if L[1] != L[2]:
+                        w[n + ".skip_connection.weight"] = ops.pack_conv_weight(g(n + ".skip_connection.weight"))
+                        w[n + ".skip_connection.bias"] = g(n + ".skip_connection.bias")
+                else:
+                    w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
+                    w[n + ".qkv.weight"] = ops.pack_conv_weight(g(n + ".qkv.weight").unsqueeze(-1))
+                    w[n + ".qkv.bias"] = g(n + ".qkv.bias")
+                    w[n + ".proj_out.weight"] = ops.pack_conv_weight(g(n + ".proj_out.weight").unsqueeze(-1))
+                    w[n + ".proj_out.bias"] = g(n + ".proj_out.bias")
+        w["film_cat.weight"] = torch.cat(fw, 0).contiguous()
+        w["film_cat.bias"] = torch.cat(fb, 0).contiguous()
+        w["out.0.weight"], w["out.0.bias"] = g("out.0.weight"), g("out.0.bias")
+        w["out.2.weight"] = ops.pack_conv_weight(g("out.2.weight"))
+        w["out.2.bias"] = g("out.2.bias")
+        half = self.model_channels // 2
+        w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        self.w = w
+        self._ws = None
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, B):
+        if self._ws is None or self._ws_B < B:
+            res, mp = self.image_size, 0
+            while res >= 8:
+                mp = max(mp, ops.gn_nchunk(res * res, min(self.max_ch, 4096)))
+                res //= 2
+            self._ws = ops.GroupNormWorkspace(self.device, B, self.max_ch, B * mp * 32 * 2)
+            self._ws_B = B
+        return self._ws
+
+    def _gn(self, x0, x1, name, film=None):
+        f, fs = (None, 0) if film is None else (film, self.film_total)
+        return ops.group_norm_affine(x0, x1, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws,
+                                     film=f, film_stride=fs)
+
+    def _res(self, n, L, x0, x1, film_all):
+        w = self.w
+        cin, cout, mode = L[1], L[2], L[3]
+        film = film_all[:, self._film_off[n]:]
+        gn1 = self._gn(x0, x1, n + ".in_layers.0")
+        if mode == "down":
+            hp = ops.avgpool2_nhwc(x0, gn=gn1, silu=True)
+            xs = ops.avgpool2_nhwc(x0)
+            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"])
+            res_ups = False
+        elif mode == "up":
+            h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, gn=gn1, gn_silu=True, ups=True,
+                           bias=w[n + ".in_layers.2.bias"])
+            xs, res_ups = x0, True
+        else:
+            h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, src1=x1, gn=gn1, gn_silu=True,
+                           bias=w[n + ".in_layers.2.bias"])
+            res_ups = False
+            if cin != cout:
+                xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
+                                bias=w[n + ".skip_connection.bias"])
+            else:
+                assert x1 is None
+                xs = x0
+        gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
+        return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
+                          bias=w[n + ".out_layers.3.bias"], res=xs, res_ups=res_ups)
+
+    def _attn(self, n, x):
+        w = self.w
+        B, H, W, C = x.shape
+        T = H * W
+        hc = self.num_head_channels if self.num_head_channels != -1 else C // self.num_heads
+        nh = C // hc
+        gn = self._gn(x, None, n + ".norm")
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        flat = qkv.view(-1)
+        S = torch.empty(B * nh, T, T, dtype=torch.float32, device=x.device)
+        ops.bgemm(flat, flat[hc:], S, T, T, hc, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
+                  sA=(T * 3 * C, 3 * hc), sB=(T * 3 * C, 3 * hc), sC=(nh * T * T, T * T))
+        ops.softmax_rows_(S, B * nh * T, T, T, 1.0 / math.sqrt(hc))      # (q*s).(k*s), s = hc^-1/4
+        o = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        ops.bgemm(S, flat[2 * hc:], o, T, hc, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B * nh, inner=nh,
+                  sA=(nh * T * T, T * T), sB=(T * 3 * C, 3 * hc), sC=(T * C, hc))
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+
+    def _run(self, prefix, layers, h, skip, film_all):
+        for j, L in enumerate(layers):
+            n = f"{prefix}.{j}"
+            if L[0] == "conv":
+                h = ops.conv2d(h, self.w[n + ".weight"], L[2], 3, bias=self.w[n + ".bias"])
+            elif L[0] == "res":
+                h = self._res(n, L, h, skip if j == 0 else None, film_all)
+            else:
+                h = self._attn(n, h)
+        return h
+
+    def forward(self, x, timesteps, y=None):
+        if self.w is None:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        w = self.w
+        B = x.shape[0]
+        self._workspace(B)
+        t = timesteps.to(device=x.device, dtype=torch.float32).contiguous()
+        emb = ops.timestep_embedding(t, w["time.freq"], order=1)
+        emb = ops.linear(emb, w["time_embed.0.weight"], w["time_embed.0.bias"])
+        emb = ops.linear(emb, w["time_embed.2.weight"], w["time_embed.2.bias"], silu_in=True)
+        if self.num_classes is not None:
+            assert y.shape == (B,)
+            ops.embedding_add_(emb, w["label_emb.weight"], y)
+        film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
+
+        h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD)
+        hs = []
+        for i, layers in enumerate(self.input_blocks):
+            h = self._run(f"input_blocks.{i}", layers, h, None, film_all)
+            hs.append(h)
+        h = self._run("middle_block", self.middle_block, h, None, film_all)
+        for i, layers in enumerate(self.output_blocks):
+            h = self._run(f"output_blocks.{i}", layers, h, hs.pop(), film_all)
+        gn = self._gn(h, None, "out.0")
+        return ops.conv2d(h, w["out.2.weight"], self.out_channels, 3, gn=gn, gn_silu=True, bias=w["out.2.bias"],
+                          out_nchw=True)
+
+    __call__ = forward

@@ -81,8 +81,8 @@ def pack_conv_weight(w, cin_pad=None):
     return out.contiguous()
 
 
-def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, gn=None,
-           gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0):
+def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
+           gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc."""
     B, Hs, Ws, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]
@@ -104,7 +104,7 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, Hin, Win, C0, C1, cout
     d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
-    d.badd_stride, d.tile = badd_stride, tile
+    d.badd_stride, d.tile, d.res_ups = badd_stride, tile, int(res_ups)
     need = _lib.lib().ddnm_conv2d_f32_workspace_floats(ctypes.byref(d))
     if need > 0:
         ws = _conv_workspace(src0.device, need)
@@ -140,8 +140,9 @@ def gn_nchunk(hw, c):
     return n
 
 
-def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32):
-    """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written."""
+def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0):
+    """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written.
+    `film` (rows [s | t], row stride film_stride) folds the FiLM modulation GN(x)*(1+s)+t into the affine."""
     B, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]
     C, HW = C0 + C1, H * W
@@ -153,7 +154,7 @@ def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32):
     check(L.ddnm_gn_stats_f32(_p(src0), _p(src1), B, HW, C0, C1, groups, _p(ws.partial), nchunk, _stream()),
           "ddnm_gn_stats_f32")
     check(L.ddnm_gn_finalize_f32(_p(ws.partial), nchunk, _p(gamma), _p(beta), B, HW, C, groups, eps, _p(ws.scale),
-                                 _p(ws.shift), _stream()), "ddnm_gn_finalize_f32")
+                                 _p(ws.shift), _p(film), film_stride, _stream()), "ddnm_gn_finalize_f32")
     return ws.scale, ws.shift
 
 
@@ -190,6 +191,22 @@ def timestep_embedding(t, freq, order):
     emb = torch.empty(B, 2 * half, dtype=torch.float32, device=t.device)
     check(_lib.lib().ddnm_timestep_embedding_f32(_p(t), _p(freq), _p(emb), B, half, order, _stream()),
           "ddnm_timestep_embedding_f32")
+    return emb
+
+
+def avgpool2_nhwc(x, gn=None, silu=False):
+    B, H, W, C = x.shape
+    out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=x.device)
+    sc, sh = (None, None) if gn is None else gn
+    check(_lib.lib().ddnm_avgpool2_nhwc_f32(_p(_f32c(x, "x")), _p(sc), _p(sh), int(silu), _p(out), B, H // 2, W // 2, C,
+                                            _stream()), "ddnm_avgpool2_nhwc_f32")
+    return out
+
+
+def embedding_add_(emb, table, idx):
+    idx = idx.to(device=emb.device, dtype=torch.int64).contiguous()
+    check(_lib.lib().ddnm_embedding_add_f32(_p(emb), _p(table), _p(idx), emb.shape[0], emb.shape[1], _stream()),
+          "ddnm_embedding_add_f32")
     return emb
 
 

@@ -70,6 +70,9 @@ typedef struct ddnm_conv_desc {
     int32_t tile;           /* 0 auto; 1: 128x128, 2: 64x64, 3: 128x32 (M x N per workgroup) */
     float* workspace;       /* split-K scratch (may be NULL: the kernel then runs unsplit) */
     int64_t workspace_floats;
+    int32_t res_ups;        /* 1: `res` is [B][Ho/2][Wo/2][Cout], added through a nearest x2 upsample
+                               (x_upd of an `up=True` ResBlock, guided_diffusion/unet.py:237-242) */
+    int32_t reserved;
 } ddnm_conv_desc;
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
@@ -91,7 +94,9 @@ int ddnm_gn_stats_f32(const float* src0, const float* src1, int32_t B, int32_t H
 int ddnm_gn_nchunk(int32_t HW, int32_t C);   /* chunk count `partial` must be sized for */
 int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gamma, const float* beta,
                          int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
-                         float* scale /* [B][C] */, float* shift /* [B][C] */, void* stream);
+                         float* scale /* [B][C] */, float* shift /* [B][C] */,
+                         const float* film /* optional FiLM rows [s(0..C) | t(0..C)]: GN(x)*(1+s)+t, unet.py:248-251 */,
+                         int32_t film_stride, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batched GEMM on MFMA f32:  C = alpha * A * op(B) + beta * D
@@ -126,6 +131,13 @@ int ddnm_linear_f32(const float* x, const float* W, const float* bias, float* y,
  * order 1: [cos, sin] (guided_diffusion/nn.py:103-121).  freq [half] is computed on the host. */
 int ddnm_timestep_embedding_f32(const float* t, const float* freq, float* emb, int32_t B, int32_t half,
                                 int32_t order, void* stream);
+
+/* out = mean_2x2(act(in)) on NHWC, act = optional per-(b,c) affine (+swish): the two halves of a
+ * `down=True` ResBlock (guided_diffusion/unet.py:133-140,237-242).  in is [B][2Ho][2Wo][C]. */
+int ddnm_avgpool2_nhwc_f32(const float* in, const float* gn_scale, const float* gn_shift, int32_t silu, float* out,
+                           int32_t B, int32_t Ho, int32_t Wo, int32_t C, void* stream);
+/* emb[b][:] += table[idx[b]][:]  (class-label embedding, guided_diffusion/unet.py:651-653); idx is int64. */
+int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, int32_t B, int32_t D, void* stream);
 
 /* NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad], channels >= C zero filled. */
 int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t Cpad,

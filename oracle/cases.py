@@ -77,3 +77,24 @@ def sampler_case(cfg, batch, n_iters, seed=SEED + 5):
 
 def betas():
     return schedule.beta_schedule("linear", 1e-4, 0.02, 1000)
+
+
+# ---- ADM (ImageNet) nets ------------------------------------------------------------------------
+ADM_SMALL = dict(image_size=32, num_channels=128, num_res_blocks=1, channel_mult="1,2", attention_resolutions="16",
+                 class_cond=True)
+ADM_MID = dict(image_size=64, num_channels=128, num_res_blocks=2, channel_mult="1,1,2", attention_resolutions="32,16")
+ADM_FULL = dict()      # configs/imagenet_256.yml (552.81 M parameters)
+
+
+def adm_net(kind):
+    cfg = weights.adm_config(**{"small": ADM_SMALL, "mid": ADM_MID, "full": ADM_FULL}[kind])
+    return cfg, weights.adm_state_dict(cfg, SEED)
+
+
+def adm_forward_inputs(cfg, batch, seed=SEED + 6):
+    g = torch.Generator().manual_seed(seed)
+    r = cfg.model.image_size
+    x = torch.randn(batch, 3, r, r, generator=g)
+    t = torch.tensor([430.0, 990.0, 0.0, 10.0][:batch])
+    y = torch.tensor([951, 3, 17, 999][:batch]) if cfg.model.class_cond else None
+    return x, t, y

@@ -148,3 +148,123 @@ def fill(shapes, seed):
 
 def celeba_state_dict(config, seed=1234):
     return fill(celeba_shapes(config), seed)
+
+
+# ----------------------------------------------------------------------------------------------
+# ADM UNet (guided_diffusion/unet.py::UNetModel built by script_util.create_model)
+# ----------------------------------------------------------------------------------------------
+def adm_config(image_size=256, num_channels=256, num_res_blocks=2, channel_mult="", attention_resolutions="32,16,8",
+               num_head_channels=64, learn_sigma=True, class_cond=False, use_scale_shift_norm=True,
+               resblock_updown=True):
+    """Namespace shaped like configs/imagenet_256.yml:14-47 (`use_fp16` False: the oracle runs fp32)."""
+    model = types.SimpleNamespace(type="openai", in_channels=3, out_channels=3, num_channels=num_channels,
+                                  num_heads=4, num_res_blocks=num_res_blocks,
+                                  attention_resolutions=attention_resolutions, dropout=0.0, resamp_with_conv=True,
+                                  learn_sigma=learn_sigma, use_scale_shift_norm=use_scale_shift_norm, use_fp16=False,
+                                  resblock_updown=resblock_updown, num_heads_upsample=-1, var_type="fixedsmall",
+                                  num_head_channels=num_head_channels, image_size=image_size, class_cond=class_cond,
+                                  use_new_attention_order=False, channel_mult=channel_mult)
+    data = types.SimpleNamespace(dataset="ImageNet", image_size=image_size, channels=3, logit_transform=False,
+                                 uniform_dequantization=False, gaussian_dequantization=False, random_flip=True,
+                                 rescaled=True, num_workers=0, subset_1k=True, out_of_dist=False)
+    diffusion = types.SimpleNamespace(beta_schedule="linear", beta_start=1e-4, beta_end=0.02,
+                                      num_diffusion_timesteps=1000)
+    sampling = types.SimpleNamespace(batch_size=1)
+    tt = types.SimpleNamespace(T_sampling=100, travel_length=1, travel_repeat=1)
+    return types.SimpleNamespace(model=model, data=data, diffusion=diffusion, sampling=sampling, time_travel=tt)
+
+
+def adm_channel_mult(m):
+    """script_util.py:148-160."""
+    if m.channel_mult == "":
+        return {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}[m.image_size]
+    return tuple(int(v) for v in m.channel_mult.split(","))
+
+
+def adm_blocks(config):
+    """Block structure of UNetModel.__init__ (unet.py:470-617) as plain data:
+    input[i] / middle / output[i] = list of layers, each ("conv", cin, cout) | ("res", cin, cout, mode)
+    | ("attn", c) with mode in {"", "down", "up"}."""
+    m = config.model
+    mc = m.num_channels
+    mult = adm_channel_mult(m)
+    attn_ds = tuple(m.image_size // int(r) for r in m.attention_resolutions.split(","))
+    ch = int(mult[0] * mc)
+    inp = [[("conv", m.in_channels, ch)]]
+    chans = [ch]
+    ds = 1
+    for level, mu in enumerate(mult):
+        for _ in range(m.num_res_blocks):
+            layers = [("res", ch, int(mu * mc), "")]
+            ch = int(mu * mc)
+            if ds in attn_ds:
+                layers.append(("attn", ch))
+            inp.append(layers)
+            chans.append(ch)
+        if level != len(mult) - 1:
+            assert m.resblock_updown, "conv_resample Downsample path is not used by the ImageNet configs"
+            inp.append([("res", ch, ch, "down")])
+            chans.append(ch)
+            ds *= 2
+    mid = [("res", ch, ch, ""), ("attn", ch), ("res", ch, ch, "")]
+    out = []
+    for level, mu in list(enumerate(mult))[::-1]:
+        for i in range(m.num_res_blocks + 1):
+            ich = chans.pop()
+            layers = [("res", ch + ich, int(mc * mu), "")]
+            ch = int(mc * mu)
+            if ds in attn_ds:
+                layers.append(("attn", ch))
+            if level and i == m.num_res_blocks:
+                layers.append(("res", ch, ch, "up"))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out, ch
+
+
+def adm_shapes(config):
+    m = config.model
+    mc = m.num_channels
+    ted = 4 * mc
+    out_channels = 6 if m.learn_sigma else 3
+    s = OrderedDict()
+    _lin(s, "time_embed.0", ted, mc)
+    _lin(s, "time_embed.2", ted, ted)
+    if m.class_cond:
+        s["label_emb.weight"] = (1000, ted)
+
+    def layer(prefix, L):
+        if L[0] == "conv":
+            _conv(s, prefix, L[2], L[1], 3)
+        elif L[0] == "res":
+            _, cin, cout, _mode = L
+            _gn(s, prefix + ".in_layers.0", cin)
+            _conv(s, prefix + ".in_layers.2", cout, cin, 3)
+            _lin(s, prefix + ".emb_layers.1", (2 * cout if m.use_scale_shift_norm else cout), ted)
+            _gn(s, prefix + ".out_layers.0", cout)
+            _conv(s, prefix + ".out_layers.3", cout, cout, 3)
+            if cin != cout:
+                _conv(s, prefix + ".skip_connection", cout, cin, 1)
+        else:
+            c = L[1]
+            _gn(s, prefix + ".norm", c)
+            s[prefix + ".qkv.weight"], s[prefix + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
+            s[prefix + ".proj_out.weight"], s[prefix + ".proj_out.bias"] = (c, c, 1), (c,)
+
+    inp, mid, out, ch = adm_blocks(config)
+    for i, layers in enumerate(inp):
+        for j, L in enumerate(layers):
+            layer(f"input_blocks.{i}.{j}", L)
+    for j, L in enumerate(mid):
+        layer(f"middle_block.{j}", L)
+    for i, layers in enumerate(out):
+        for j, L in enumerate(layers):
+            layer(f"output_blocks.{i}.{j}", L)
+    _gn(s, "out.0", ch)
+    _conv(s, "out.2", out_channels, ch, 3)
+    return s
+
+
+def adm_state_dict(config, seed=1234):
+    """Every tensor random -- including the zero_module'd ones (nn.py:68), else eps == 0 identically."""
+    return fill(adm_shapes(config), seed)

@@ -57,10 +57,49 @@ def sub(t, step=8):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
+def make_adm():
+    """ADM UNetModel (guided_diffusion/unet.py via script_util.create_model), fp32, seeded weights with the
+    zero_module'd tensors re-randomised: key list, forwards at three sizes, one sampler run."""
+    ns = ref_import.load()
+    R = ns.svd_operators
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for kind, batch in (("small", 2), ("mid", 2), ("full", 1)):
+        cfg, sd = cases.adm_net(kind)
+        ref = ns.script_util.create_model(**vars(cfg.model))
+        if kind == "full":
+            keys = [[k, list(v.shape)] for k, v in ref.state_dict().items()]
+            json.dump(keys, open(os.path.join(HERE, "adm_state_dict_keys.json"), "w"))
+        ref.load_state_dict(sd)
+        ref.eval()
+        x, t, y = cases.adm_forward_inputs(cfg, batch)
+        with torch.no_grad():
+            e = ref(x, t, y) if y is not None else ref(x, t)
+        out[f"{kind}_eps"] = e.numpy() if kind != "full" else sub(e, 4)
+        out[f"{kind}_stats"] = np.array([e.double().mean().item(), e.double().std().item(), e.double().abs().sum().item()])
+        if kind == "mid":       # sampler: colorization + inpainting with time travel through the reference loop
+            cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 20, 2, 2
+            n_it = len(schedule.jump_times(20, 2, 2)) - 1
+            d = cfg.data.image_size
+            for name in ("colorization", "inpainting"):
+                x_orig, x_T, tape = cases.sampler_case(cfg, 2, n_it)
+                op = ref_operator(R, name, d)
+                yy = op.A(x_orig)
+                with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+                    xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, yy, cls_fn=None,
+                                                         classes=None, config=cfg)
+                out[f"mid_{name}_x"] = xs[0].numpy()
+                out[f"mid_{name}_x0"] = x0s[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "adm_forward.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     args = ap.parse_args()
+    if args.adm_only:
+        return make_adm()
     ns = ref_import.load()
     R = ns.svd_operators
     torch.set_num_threads(os.cpu_count())
