@@ -26,6 +26,7 @@ class ConvDesc(Structure):
         ("badd_stride", c_int32), ("tile", c_int32),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("res_ups", c_int32), ("reserved", c_int32),
+        ("stats_out", c_void_p),
     ]
 
 
@@ -53,6 +54,10 @@ PROTOTYPES = {
     "ddnm_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
+    "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                             c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
+                                             c_void_p]),
     "ddnm_gn_stats_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_int32, c_void_p]),
     "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),

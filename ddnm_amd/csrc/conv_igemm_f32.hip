@@ -73,8 +73,8 @@ __device__ __forceinline__ TileMap make_tilemap(const ConvArgs& p, int m_tile) {
 
 // ---- shared epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 template <int WM, int WN, int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int slice,
-                                              f32x16 (&acc)[MT][NT]) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int m_tile, int slice,
+                                              f32x16 (&acc)[MT][NT], float* lds) {
     constexpr int BN = WN * NT * 32;
     const ddnm_conv_desc& d = p.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,6 +84,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
     float* __restrict__ ws = partial ? p.ws + (size_t)slice * d.B * d.Ho * d.Wo * d.Cout : nullptr;
     const float* __restrict__ res = d.res;
     float* __restrict__ out = d.out;
+    const bool want_stats = d.stats_out != nullptr && !partial;
+    float cs[NT], cq[NT];              // per-lane column (= output channel) partial sum / sum of squares
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
@@ -95,25 +99,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            size_t o[16];
+            // 32-bit element offsets (tensors here are < 2^31 elements): 16 registers instead of 32
+            unsigned o[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
                 int oy, ox;
                 tm.pixel(row, oy, ox);
-                o[r] = d.out_nchw && !partial ? ((size_t)(tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox
-                                              : ((size_t)(tm.img * d.Ho + oy) * d.Wo + ox) * d.Cout + n;
+                const unsigned pix = (unsigned)((tm.img * d.Ho + oy) * d.Wo + ox);
+                if (d.res_ups && res && !partial) {
+                    o[r] = pix;                 // resolved below: two different address forms are needed
+                } else {
+                    o[r] = d.out_nchw && !partial ? (unsigned)(((tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox)
+                                                  : pix * (unsigned)d.Cout + (unsigned)n;
+                }
             }
             // all 16 residual loads of this 32x32 tile are issued before the first store (a
             // load -> add -> store chain per element would serialise 16 HBM round trips)
             float rv[16];
             if (res && !partial && d.res_ups) {      // residual read through a nearest x2 upsample
+                const unsigned hw = (unsigned)(d.Ho * d.Wo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                    int oy, ox;
-                    tm.pixel(row, oy, ox);
-                    rv[r] = res[((size_t)(tm.img * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) * d.Cout + n];
+                    const unsigned pin = o[r] - (unsigned)tm.img * hw;
+                    const unsigned oy = pin / (unsigned)d.Wo, ox = pin - oy * (unsigned)d.Wo;
+                    rv[r] = res[(size_t)((tm.img * (d.Ho >> 1) + (int)(oy >> 1)) * (d.Wo >> 1) + (int)(ox >> 1)) * d.Cout + n];
+                    o[r] = o[r] * (unsigned)d.Cout + (unsigned)n;
                 }
             } else {
 #pragma unroll
@@ -124,6 +135,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
                 const float v = acc[i][j][r] + add + rv[r];
                 if (partial) ws[o[r]] = v;
                 else out[o[r]] = v;
+                cs[j] += v;
+                cq[j] += v * v;
+            }
+        }
+    }
+    // GroupNorm statistics of the tensor just produced, emitted here so the consumer's GroupNorm needs no
+    // extra pass over HBM: per (M tile, channel) fp32 partials over the tile's rows, fixed order.
+    if (want_stats) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            cs[j] += __shfl_xor(cs[j], 32);
+            cq[j] += __shfl_xor(cq[j], 32);
+        }
+        __syncthreads();                       // every wave is done with the operand tiles in LDS
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int c = (wn * NT + j) * 32 + lane;
+                lds[(wm * BN + c) * 2 + 0] = cs[j];
+                lds[(wm * BN + c) * 2 + 1] = cq[j];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < BN; c += 256) {
+            const int n = n_tile * BN + c;
+            if (n < d.Cout) {
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) { a += lds[(w * BN + c) * 2]; q += lds[(w * BN + c) * 2 + 1]; }
+                d.stats_out[((size_t)m_tile * d.Cout + n) * 2 + 0] = a;
+                d.stats_out[((size_t)m_tile * d.Cout + n) * 2 + 1] = q;
             }
         }
     }
@@ -335,14 +377,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         }
     }
 #endif
-    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, slice, acc);
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, Hs);
 }
 
 // =====================================================================================
 // generic per-tap gather (1x1, strided 3x3)
 // =====================================================================================
 template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_gather_f32_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const ConvArgs p) {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread for the A / B tile copies
     __shared__ __attribute__((aligned(16))) float As[BM * LDT];
@@ -439,7 +481,7 @@ __global__ __launch_bounds__(256) void conv_gather_f32_kernel(const ConvArgs p) 
         if (it + 1 < it_end) prefetch(it + 1);
         mfma_tile_step<MT, NT>(a_frag, b_frag, acc);
     }
-    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, slice, acc);
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, As);
 }
 
 // =====================================================================================
@@ -531,6 +573,13 @@ extern "C" int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d) {
     return pl.BN;
 }
 
+extern "C" int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d) {
+    ConvPlan pl;
+    if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
+    if (pl.ksplit > 1 || d->out_nchw) return 0;         // split-K / NCHW launches do not emit statistics
+    return d->Ho * d->Wo / pl.BM;
+}
+
 extern "C" int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d) {
     ConvPlan pl;
     if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
@@ -560,6 +609,7 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
         if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;      // no scratch: run unsplit
     }
+    if (d->stats_out && (pl.ksplit > 1 || d->out_nchw)) return DDNM_E_SHAPE;  // see ddnm_conv2d_f32_stats_tiles
     ConvArgs p;
     p.d = *d;
     p.Cin = d->C0 + d->C1;

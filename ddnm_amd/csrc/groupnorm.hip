@@ -127,3 +127,79 @@ extern "C" int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const
                        HW, C, groups, eps, scale, shift, film, film_stride);
     return 0;
 }
+
+// ---- finalize from the per-(M tile, channel) partials emitted by the producing convolution's epilogue
+// (conv_igemm_f32.hip).  The input may be the channel concat of two tensors with different tilings.
+// grid (B, groups): one workgroup per (sample, group); 256 threads stride over the group's (tile, channel)
+// partials, fp64 sums combined in a fixed order.
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __restrict__ part0, int tpi0, int C0,
+                                                                const float* __restrict__ part1, int tpi1, int C1,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int HW, int groups,
+                                                                float eps, float* __restrict__ scale,
+                                                                float* __restrict__ shift,
+                                                                const float* __restrict__ film, int film_stride) {
+    __shared__ double red[256][2];
+    __shared__ float mean_s, rstd_s;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const int C = C0 + C1, cpg = C / groups;
+    const int c_lo = g * cpg;
+    double a = 0.0, q = 0.0;
+    // channels of the group below C0 come from part0, the rest from part1
+    const int n0 = max(0, min(C0, c_lo + cpg) - c_lo);
+    const int n1 = cpg - n0;
+    const int items0 = n0 * tpi0, items1 = n1 * tpi1;
+    for (int it = tid; it < items0; it += 256) {
+        const int t = it / n0, c = c_lo + (it - t * n0);
+        const float2 v = *reinterpret_cast<const float2*>(part0 + (((size_t)b * tpi0 + t) * C0 + c) * 2);
+        a += (double)v.x;
+        q += (double)v.y;
+    }
+    const int c1_lo = c_lo + n0 - C0;
+    for (int it = tid; it < items1; it += 256) {
+        const int t = it / n1, c = c1_lo + (it - t * n1);
+        const float2 v = *reinterpret_cast<const float2*>(part1 + (((size_t)b * tpi1 + t) * C1 + c) * 2);
+        a += (double)v.x;
+        q += (double)v.y;
+    }
+    red[tid][0] = a;
+    red[tid][1] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {       // fixed-shape tree: deterministic
+        if (tid < s) { red[tid][0] += red[tid + s][0]; red[tid][1] += red[tid + s][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)HW * (double)cpg;
+        const double mean = red[0][0] / cnt;
+        double var = red[0][1] / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mean_s = (float)mean;
+        rstd_s = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = c_lo + tid; c < c_lo + cpg; c += 256) {
+        float sc = rstd_s * gamma[c];
+        float sh = beta[c] - mean_s * sc;
+        if (film) {
+            const float s1 = 1.0f + film[(size_t)b * film_stride + c];
+            sc = sc * s1;
+            sh = sh * s1 + film[(size_t)b * film_stride + C + c];
+        }
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = sh;
+    }
+}
+
+extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int32_t C0, const float* part1,
+                                          int32_t tpi1, int32_t C1, const float* gamma, const float* beta, int32_t B,
+                                          int32_t HW, int32_t groups, float eps, float* scale, float* shift,
+                                          const float* film, int32_t film_stride, void* stream) {
+    if (!part0 || !gamma || !beta || !scale || !shift || B <= 0 || tpi0 <= 0 || C0 <= 0) return DDNM_E_BADARG;
+    if (C1 > 0 && (!part1 || tpi1 <= 0)) return DDNM_E_BADARG;
+    const int C = C0 + C1;
+    if (groups <= 0 || C % groups) return DDNM_E_SHAPE;
+    DDNM_LAUNCH(gn_finalize_tiles_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, part0, tpi0, C0, part1, tpi1,
+                C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride);
+    return 0;
+}

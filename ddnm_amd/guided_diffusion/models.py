@@ -263,7 +263,7 @@ class Model:
         w, n = self.w, rb.name
         gn1 = self._gn(x0, x1, n + ".norm1")
         h = ops.conv2d(x0, w[n + ".conv1.weight"], rb.cout, 3, src1=x1, gn=gn1, gn_silu=True,
-                       badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total)
+                       badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total, emit_stats=True)
         gn2 = self._gn(h, None, n + ".norm2")
         if rb.cin != rb.cout:
             xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"])
@@ -271,23 +271,23 @@ class Model:
             assert x1 is None
             xs = x0
         return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True, bias=w[n + ".conv2.bias"],
-                          res=xs)
+                          res=xs, emit_stats=True)
 
     def _attn(self, a, x):
         w, n = self.w, a.name
-        B, H, W, C = x.shape
+        B, H, W, C = x.t.shape
         T = H * W
         gn = self._gn(x, None, n + ".norm")
         qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
-        S = torch.empty(B, T, T, dtype=torch.float32, device=x.device)
+        S = torch.empty(B, T, T, dtype=torch.float32, device=qkv.device)
         q, k, v = qkv.view(-1)[0:], qkv.view(-1)[C:], qkv.view(-1)[2 * C:]
         ops.bgemm(q, k, S, T, T, C, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B,
                   sA=(T * 3 * C, 0), sB=(T * 3 * C, 0), sC=(T * T, 0))
         ops.softmax_rows_(S, B * T, T, T, float(int(C) ** (-0.5)))
-        o = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
         ops.bgemm(S, v, o, T, C, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B,
                   sA=(T * T, 0), sB=(T * 3 * C, 0), sC=(T * C, 0))
-        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
 
     def forward(self, x, t):
         if self.w is None:
@@ -303,7 +303,7 @@ class Model:
         tproj = ops.linear(temb, w["temb_proj_cat.weight"], w["temb_proj_cat.bias"], silu_in=True)
 
         xin = ops.nchw_to_nhwc_pad(x.contiguous(), CIN_PAD)
-        hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"])]
+        hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"], emit_stats=True)]
         for lvl, (blocks, attns, has_down, c) in enumerate(self.down):
             for ib, rb in enumerate(blocks):
                 h = self._resblock(rb, hs[-1], None, tproj)
@@ -316,7 +316,7 @@ class Model:
                 # F.pad(x, (0,1,0,1)) + 3x3 stride 2 (models.py:68-71): pad=0 on top/left, the
                 # bottom/right zero row/column comes from the loader's bounds check
                 hs.append(ops.conv2d(src, w[n + ".weight"], c, 3, bias=w[n + ".bias"], stride=2, pad=0,
-                                     out_hw=(src.shape[1] // 2, src.shape[2] // 2)))
+                                     out_hw=(src.t.shape[1] // 2, src.t.shape[2] // 2), emit_stats=True))
         h = hs[-1]
         h = self._resblock(self.mid[0], h, None, tproj)
         h = self._attn(self.mid[1], h)
@@ -329,7 +329,7 @@ class Model:
                     h = self._attn(attns[ib], h)
             if has_up:
                 n = f"up.{lvl}.upsample.conv"
-                h = ops.conv2d(h, w[n + ".weight"], c, 3, bias=w[n + ".bias"], ups=True)
+                h = ops.conv2d(h, w[n + ".weight"], c, 3, bias=w[n + ".bias"], ups=True, emit_stats=True)
         gn = self._gn(h, None, "norm_out")
         return ops.conv2d(h, w["conv_out.weight"], self.out_ch, 3, gn=gn, gn_silu=True, bias=w["conv_out.bias"],
                           out_nchw=True)

@@ -247,17 +247,17 @@ class UNetModel:
         film = film_all[:, self._film_off[n]:]
         gn1 = self._gn(x0, x1, n + ".in_layers.0")
         if mode == "down":
-            hp = ops.avgpool2_nhwc(x0, gn=gn1, silu=True)
-            xs = ops.avgpool2_nhwc(x0)
-            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"])
+            hp = ops.avgpool2_nhwc(x0.t, gn=gn1, silu=True)
+            xs = ops.avgpool2_nhwc(x0.t)
+            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True)
             res_ups = False
         elif mode == "up":
             h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, gn=gn1, gn_silu=True, ups=True,
-                           bias=w[n + ".in_layers.2.bias"])
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
             xs, res_ups = x0, True
         else:
             h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, src1=x1, gn=gn1, gn_silu=True,
-                           bias=w[n + ".in_layers.2.bias"])
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
             res_ups = False
             if cin != cout:
                 xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
@@ -267,31 +267,31 @@ class UNetModel:
                 xs = x0
         gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
         return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
-                          bias=w[n + ".out_layers.3.bias"], res=xs, res_ups=res_ups)
+                          bias=w[n + ".out_layers.3.bias"], res=xs, res_ups=res_ups, emit_stats=True)
 
     def _attn(self, n, x):
         w = self.w
-        B, H, W, C = x.shape
+        B, H, W, C = x.t.shape
         T = H * W
         hc = self.num_head_channels if self.num_head_channels != -1 else C // self.num_heads
         nh = C // hc
         gn = self._gn(x, None, n + ".norm")
         qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
         flat = qkv.view(-1)
-        S = torch.empty(B * nh, T, T, dtype=torch.float32, device=x.device)
+        S = torch.empty(B * nh, T, T, dtype=torch.float32, device=qkv.device)
         ops.bgemm(flat, flat[hc:], S, T, T, hc, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
                   sA=(T * 3 * C, 3 * hc), sB=(T * 3 * C, 3 * hc), sC=(nh * T * T, T * T))
         ops.softmax_rows_(S, B * nh * T, T, T, 1.0 / math.sqrt(hc))      # (q*s).(k*s), s = hc^-1/4
-        o = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
         ops.bgemm(S, flat[2 * hc:], o, T, hc, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B * nh, inner=nh,
                   sA=(nh * T * T, T * T), sB=(T * 3 * C, 3 * hc), sC=(T * C, hc))
-        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
 
     def _run(self, prefix, layers, h, skip, film_all):
         for j, L in enumerate(layers):
             n = f"{prefix}.{j}"
             if L[0] == "conv":
-                h = ops.conv2d(h, self.w[n + ".weight"], L[2], 3, bias=self.w[n + ".bias"])
+                h = ops.conv2d(h, self.w[n + ".weight"], L[2], 3, bias=self.w[n + ".bias"], emit_stats=True)
             elif L[0] == "res":
                 h = self._res(n, L, h, skip if j == 0 else None, film_all)
             else:

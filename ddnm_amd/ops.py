@@ -81,9 +81,27 @@ def pack_conv_weight(w, cin_pad=None):
     return out.contiguous()
 
 
+import os as _os
+_NO_FUSED_GN = _os.environ.get("DDNM_NO_FUSED_GN") == "1"      # A/B switch for profiling
+
+
+class Act:
+    """An NHWC activation plus, when its producer could emit them, the GroupNorm partials of it
+    (per-(M tile, channel) sum / sum of squares written by the convolution epilogue)."""
+    __slots__ = ("t", "stats", "tiles")
+
+    def __init__(self, t, stats=None, tiles=0):
+        self.t, self.stats, self.tiles = t, stats, tiles
+
+
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
-           gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0):
-    """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc."""
+           gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
+           emit_stats=False):
+    """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
+    With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them)."""
+    src0 = src0.t if isinstance(src0, Act) else src0
+    src1 = src1.t if isinstance(src1, Act) else src1
+    res = res.t if isinstance(res, Act) else res
     B, Hs, Ws, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]
     Hin, Win = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
@@ -105,6 +123,12 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
     d.badd_stride, d.tile, d.res_ups = badd_stride, tile, int(res_ups)
+    stats, tiles = None, 0
+    if emit_stats and not _NO_FUSED_GN:
+        tiles = _lib.lib().ddnm_conv2d_f32_stats_tiles(ctypes.byref(d))
+        if tiles > 0:
+            stats = torch.empty(B * tiles * cout * 2, dtype=torch.float32, device=src0.device)
+            d.stats_out = stats.data_ptr()
     need = _lib.lib().ddnm_conv2d_f32_workspace_floats(ctypes.byref(d))
     if need > 0:
         ws = _conv_workspace(src0.device, need)
@@ -120,6 +144,8 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
         e1.record()
         _timer.records.append((variant, 2.0 * B * Ho * Wo * cout * ksize * ksize * (C0 + C1), e0, e1))
+    if emit_stats:
+        return Act(out, stats, tiles)
     return out
 
 
@@ -142,10 +168,23 @@ def gn_nchunk(hw, c):
 
 def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0):
     """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written.
-    `film` (rows [s | t], row stride film_stride) folds the FiLM modulation GN(x)*(1+s)+t into the affine."""
+    `film` (rows [s | t], row stride film_stride) folds the FiLM modulation GN(x)*(1+s)+t into the affine.
+    src0 / src1 may be tensors or `Act`s; when every source carries conv-epilogue partials the statistics
+    come from those (no pass over the activation), otherwise from the stand-alone statistics kernel."""
+    a0 = src0 if isinstance(src0, Act) else Act(src0)
+    a1 = None if src1 is None else (src1 if isinstance(src1, Act) else Act(src1))
+    src0, src1 = a0.t, (None if a1 is None else a1.t)
     B, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]
     C, HW = C0 + C1, H * W
+    if a0.stats is not None and (a1 is None or a1.stats is not None):
+        if ws.scale.numel() < B * C:
+            raise ValueError("GroupNorm workspace too small")
+        check(_lib.lib().ddnm_gn_finalize_tiles_f32(_p(a0.stats), a0.tiles, C0, None if a1 is None else _p(a1.stats),
+                                                    0 if a1 is None else a1.tiles, C1, _p(gamma), _p(beta), B, HW,
+                                                    groups, eps, _p(ws.scale), _p(ws.shift), _p(film), film_stride,
+                                                    _stream()), "ddnm_gn_finalize_tiles_f32")
+        return ws.scale, ws.shift
     nchunk = gn_nchunk(HW, C)
     need = B * nchunk * groups * 2
     if ws.partial.numel() < need or ws.scale.numel() < B * C:

@@ -73,6 +73,9 @@ typedef struct ddnm_conv_desc {
     int32_t res_ups;        /* 1: `res` is [B][Ho/2][Wo/2][Cout], added through a nearest x2 upsample
                                (x_upd of an `up=True` ResBlock, guided_diffusion/unet.py:237-242) */
     int32_t reserved;
+    float* stats_out;       /* optional [B*tiles][Cout][2]: per-(M tile, channel) sum / sum of squares of `out`,
+                               tiles = ddnm_conv2d_f32_stats_tiles(d) per image; feeds ddnm_gn_finalize_tiles_f32 so
+                               the consumer's GroupNorm never re-reads the tensor */
 } ddnm_conv_desc;
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
@@ -81,6 +84,8 @@ int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d);
 /* Scratch floats the auto plan wants for this desc (0: no split-K); low-resolution layers whose tile
  * grid cannot fill 256 CUs split their channel chunks over several workgroups per tile. */
 int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d);
+/* M tiles per image of the auto plan if this launch can emit `stats_out` (0: split-K or NCHW launch). */
+int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
@@ -97,6 +102,13 @@ int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gam
                          float* scale /* [B][C] */, float* shift /* [B][C] */,
                          const float* film /* optional FiLM rows [s(0..C) | t(0..C)]: GN(x)*(1+s)+t, unet.py:248-251 */,
                          int32_t film_stride, void* stream);
+
+/* GroupNorm affine from the partials a convolution epilogue emitted (`stats_out`); the input may be the
+ * channel concat of two tensors (part1 / tpi1 / C1, or NULL / 0 / 0). */
+int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tiles_per_img0, int32_t C0, const float* part1,
+                               int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
+                               int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,
+                               int32_t film_stride, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batched GEMM on MFMA f32:  C = alpha * A * op(B) + beta * D

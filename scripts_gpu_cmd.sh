@@ -1,5 +1,6 @@
 cd /root/repo
-python bench.py --steps 2 --warmup 1 2>&1 | tail -1 | tee gpurun_out/bench_line.json
-export TMPDIR=/tmp; cd /tmp
-rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_r01 -o bench -- python /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /root/repo/gpurun_out/prof_bench.log 2>&1
-tail -1 /root/repo/gpurun_out/prof_bench.log | cut -c1-300
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q 2>&1 | tail -3
+for i in 1 2; do
+DDNM_NO_FUSED_GN=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('unfused', d['value'], d['ms_per_step'])"
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused  ', d['value'], d['ms_per_step'])"
+done

@@ -263,3 +263,32 @@ def test_renoise_and_finalize(hip):
     assert torch.equal(got.cpu(), 0.8 * x0 + nz * 0.6)
     assert torch.equal(img.cpu(), torch.clamp((x0 + 1.0) / 2.0, 0.0, 1.0))
     assert (psnr.cpu().float() - sampler.psnr(x0, xo)).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------ GroupNorm statistics from the conv epilogue
+@pytest.mark.parametrize("B,C0,C1,H", [(4, 256, 0, 64), (4, 256, 256, 64), (8, 128, 128, 64), (2, 128, 384, 128)])
+def test_groupnorm_from_conv_epilogue_stats(hip, B, C0, C1, H):
+    """The producing convolutions emit per-(tile, channel) partials; the consumer's GroupNorm affine is built
+    from them (two sources = skip concat, possibly with different tilings) without re-reading the tensors."""
+    from ddnm_amd import ops
+    x = gen(B, 128, H, H, seed=50)
+    w0 = gen(C0, 128, 3, 3, seed=51, scale=0.04)
+    a = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w0.cuda()), C0, 3, emit_stats=True)
+    ref0 = F.conv2d(x, w0, None, padding=1)
+    assert a.stats is not None and a.tiles > 0
+    a1, ref1 = None, None
+    if C1:
+        w1 = gen(C1, 128, 1, 1, seed=52, scale=0.1)
+        a1 = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w1.cuda()), C1, 1, emit_stats=True, tile=2)
+        ref1 = F.conv2d(x, w1, None)
+        assert a1.stats is not None
+    C = C0 + C1
+    gamma, beta = 1 + 0.1 * gen(C, seed=53), 0.1 * gen(C, seed=54)
+    xin = ref0 if ref1 is None else torch.cat([ref0, ref1], 1)
+    ref = F.group_norm(xin, 32, gamma, beta, eps=1e-6)
+    ws = ops.GroupNormWorkspace("cuda", B, C, 16)          # partial buffer unused on this path
+    sc, sh = ops.group_norm_affine(a, a1, gamma.cuda(), beta.cuda(), 1e-6, ws)
+    torch.cuda.synchronize()
+    sc, sh = sc[:B * C].reshape(B, C).cpu(), sh[:B * C].reshape(B, C).cpu()
+    got = xin * sc[:, :, None, None] + sh[:, :, None, None]
+    assert rel(got, ref) < 3e-6
