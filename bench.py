@@ -187,9 +187,18 @@ def main():
         name, r = dom
         total_ms = sum(v["ms"] for v in summ.values())
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        # HBM traffic / MFMA-busy of the same kernel come from separate rocprofv3 --pmc passes (bench.py cannot
+        # run under the profiler itself); tools/pmc_summary.py writes them to profiles/.
+        traffic, mfma_busy = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_busy_frac_weighted")
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+            "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_dominant_kernel.json",
+            "mfma_busy_pmc": mfma_busy,
             "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
             "avg_flops_per_launch": r["flops"] / r["launches"],
             "share_of_conv_time": round(r["ms"] / total_ms, 4),

@@ -1,6 +1,6 @@
-cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -q 2>&1 | tail -3
-for i in 1 2; do
-DDNM_NO_FUSED_GN=1 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('unfused', d['value'], d['ms_per_step'])"
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused  ', d['value'], d['ms_per_step'])"
-done
+export TMPDIR=/tmp; cd /tmp
+O=/root/repo/gpurun_out
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python /root/repo/tools/forward_once.py 2 > $O/pmc1.log 2>&1; tail -2 $O/pmc1.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python /root/repo/tools/forward_once.py 2 > $O/pmc2.log 2>&1; tail -1 $O/pmc2.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python /root/repo/tools/forward_once.py 2 > $O/pmc3.log 2>&1; tail -1 $O/pmc3.log
+ls -la $O/pmc_mfma $O/pmc_fetch | head -20
