@@ -1,0 +1,263 @@
+// 3x3 implicit-GEMM convolution on v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate), gfx950.
+//
+// Precision contract of the reference's ImageNet path: conv weights and torso activations are fp16,
+// GroupNorm / softmax / embeddings fp32 (guided_diffusion/fp16_util.py:15-22, nn.py:17-19,
+// unet.py:352).  Here activations stay fp32 in HBM; they are rounded to fp16 only while the
+// (GroupNorm+swish'd) halo is staged into LDS, weights are fp16 in HBM, accumulation is fp32 and the
+// output (+ bias + residual) is written in fp32 -- i.e. never less precise than the reference.
+// Keeping HBM tensors fp32 leaves every other kernel of the engine untouched; at >= 500 TFLOP/s the
+// 256-channel 256x256 layers remain compute-bound (0.3 ms of MFMA vs 0.2 ms of HBM traffic).
+//
+// Structure = the fp32 halo kernel scaled for a 16x faster matrix pipe:
+//   workgroup 512 threads = 8 waves (4 x 2), wave tile 64 x 64 (2 x 2 MFMA tiles), block tile
+//   256 pixels (8 x 32 patch, halo 10 x 34) x 128 output channels, K chunk = 64 channels;
+//   LDS: halo [340][64+8] fp16 (49 KB) + weight tile [128][64+8] fp16 double-buffered (37 KB);
+//   row pitch 144 B = 36 dwords keeps ds_read_b128 conflict-free (one read = 8 k-values of a row);
+//   per tap and wave: 16 MFMAs (512 cycles) between barriers, weight tile of tap+2 in flight.
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC16 = 64;            // channels per chunk
+constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
+
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
+    constexpr int NTHREADS = WM * WN * 64;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    constexpr int MAXH = BM == 256 ? 340 : (BM == 128 ? 204 : 136);
+    constexpr int HROWS_PER_PASS = NTHREADS / 16;                 // 16 float4 per 64-channel halo row
+    constexpr int HR = (MAXH + HROWS_PER_PASS - 1) / HROWS_PER_PASS;
+    constexpr int BROWS_PER_PASS = NTHREADS / 8;                  // 8 x 16 B per 64-half weight row
+    constexpr int BR = BN / BROWS_PER_PASS;
+    static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
+    __shared__ __attribute__((aligned(16))) _Float16 Hs[MAXH * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BN * LDH];
+    __shared__ __attribute__((aligned(16))) float stat_lds[WM * BN * 2];
+
+    const ddnm_conv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
+    const int slice = blockIdx.y;
+    const TileMap tm = make_tilemap<BM>(p, m_tile);
+    const int img = tm.img;
+    const int TH = BM >> p.TW_log2, HWd = p.TW + 2;
+    const int NP = (TH + 2) * HWd;
+
+    // ---- halo loader mapping: thread -> (float4 column c4 of 16, halo rows prow + HROWS_PER_PASS*i)
+    const int c4 = tid & 15, prow = tid >> 4;
+    int hoff[HR];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int row = prow + HROWS_PER_PASS * i;
+        const int hy = row / HWd, hx = row - hy * HWd;
+        const int iy = tm.ty0 - 1 + hy, ix = tm.tx0 - 1 + hx;
+        const bool ok = row < NP && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+        hoff[i] = ok ? (img * p.Hs + sy) * p.Ws + sx : -1;
+    }
+    // ---- weight loader mapping: thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
+    const int c8 = tid & 7, brow = tid >> 3;
+    const _Float16* wbase = reinterpret_cast<const _Float16*>(d.weight) + (size_t)(n_tile * BN + brow) * 9 * p.Cin + c8 * 8;
+
+    const int nchunks = p.Cin / KC16;
+    const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
+
+    f32x4 h_st[HR];
+    uint4 b_st[BR];
+    f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
+    const bool has_gn = d.gn_scale != nullptr;
+
+    auto prefetch_halo = [&](int chunk) {
+        const int cb = chunk * KC16;
+        const float* src;
+        int cs, coff;
+        if (cb < d.C0) { src = d.src0; cs = d.C0; coff = cb; }
+        else { src = d.src1; cs = d.C1; coff = cb - d.C0; }
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
+            h_st[i] = v;
+        }
+        if (has_gn) {
+            gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + c4 * 4);
+            gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + c4 * 4);
+        }
+    };
+    auto prefetch_b = [&](int chunk, int tap) {
+        const _Float16* wp = wbase + (size_t)tap * p.Cin + chunk * KC16;
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            b_st[i] = *reinterpret_cast<const uint4*>(wp + (size_t)(BROWS_PER_PASS * i) * 9 * p.Cin);
+    };
+    auto stage_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const int row = prow + HROWS_PER_PASS * i;
+            if (row < MAXH) {
+                f32x4 v = h_st[i];
+                if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+                half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<half4*>(&Hs[row * LDH + c4 * 4]) = h;
+            }
+        }
+    };
+    auto stage_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BR; ++i)
+            *reinterpret_cast<uint4*>(&Bs[buf * BN * LDH + (brow + BROWS_PER_PASS * i) * LDH + c8 * 8]) = b_st[i];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 32 + (lane & 31);
+        const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
+        a_off[i] = (ty * HWd + tx) * LDH + (lane >> 5) * 8;
+    }
+    const _Float16* b_frag = Bs + (wn * NT * 32) * LDH + (lane & 31) * LDH + (lane >> 5) * 8;
+
+    auto mfma_tap = [&](int tap, int buf) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int tap_off = (ky * HWd + kx) * LDH;
+        const _Float16* bf = b_frag + buf * BN * LDH;
+#pragma unroll
+        for (int ks = 0; ks < KC16 / 16; ++ks) {
+            half8 a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (c_begin < c_end) {
+        prefetch_halo(c_begin);
+        prefetch_b(c_begin, 0);
+        stage_halo();
+        stage_b(0);
+        prefetch_b(c_begin, 1);
+        __syncthreads();
+        int cur = 0;
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const bool last_tap = tap == 8, more = chunk + 1 < c_end;
+                if (!last_tap || more) {
+                    stage_b(cur ^ 1);
+                    if (tap < 7) prefetch_b(chunk, tap + 2);
+                    else if (tap == 7) { if (more) { prefetch_b(chunk + 1, 0); prefetch_halo(chunk + 1); } }
+                    else if (more) prefetch_b(chunk + 1, 1);
+                }
+                mfma_tap(tap, cur);
+                __syncthreads();
+                if (last_tap && more) {
+                    stage_halo();
+                    __syncthreads();
+                }
+                cur ^= 1;
+            }
+        }
+    }
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct PlanF16 {
+    int BM, TW, TW_log2, tiles_x, ksplit;
+};
+
+static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl) {
+    const int HWo = d->Ho * d->Wo;
+    const int Cin = d->C0 + d->C1;
+    if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hin || d->Wo != d->Win) return false;
+    if (Cin % KC16 || d->C0 % KC16 || d->Cout % 128 || d->out_nchw) return false;
+    pl->BM = 256;
+    if (HWo % pl->BM) return false;
+    int tw = 32;
+    while (tw > 8 && (d->Wo % tw || d->Ho % (pl->BM / tw))) tw >>= 1;
+    if (d->Wo % tw || d->Ho % (pl->BM / tw)) return false;
+    pl->TW = tw;
+    pl->TW_log2 = tw == 32 ? 5 : (tw == 16 ? 4 : 3);
+    pl->tiles_x = d->Wo / tw;
+    const long tiles = (long)d->B * (HWo / pl->BM) * (d->Cout / 128);
+    int ks = 1;
+    const int nchunks = Cin / KC16;
+    if (tiles < 192) {
+        ks = (int)((512 + tiles - 1) / tiles);
+        if (ks > nchunks) ks = nchunks;
+        if (ks > 16) ks = 16;
+    }
+    pl->ksplit = ks;
+    return true;
+}
+
+extern "C" int ddnm_conv3x3_f16_supported(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    return d && plan_f16(d, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t ddnm_conv3x3_f16_workspace_floats(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    if (!d || !plan_f16(d, &pl)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout : 0;
+}
+
+extern "C" int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    if (!d || !plan_f16(d, &pl)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? 0 : d->Ho * d->Wo / pl.BM;
+}
+
+extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
+    if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
+    if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
+    if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
+    if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
+    if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
+    if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
+    PlanF16 pl;
+    if (!plan_f16(d, &pl)) return DDNM_E_SHAPE;
+    if (pl.ksplit > 1) {
+        const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
+        if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;
+    }
+    if (d->stats_out && pl.ksplit > 1) return DDNM_E_SHAPE;
+    ConvArgs p;
+    p.d = *d;
+    p.Cin = d->C0 + d->C1;
+    p.ntaps = 9;
+    p.Hs = d->ups ? d->Hin / 2 : d->Hin;
+    p.Ws = d->ups ? d->Win / 2 : d->Win;
+    p.m_tiles = d->B * (d->Ho * d->Wo / pl.BM);
+    p.n_tiles = d->Cout / 128;
+    p.TW = pl.TW;
+    p.TW_log2 = pl.TW_log2;
+    p.tiles_x = pl.tiles_x;
+    p.ksplit = pl.ksplit;
+    p.ws = d->workspace;
+    hipStream_t s = (hipStream_t)stream;
+    DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
+    if (pl.ksplit > 1) {
+        const size_t total4 = (size_t)d->B * d->Ho * d->Wo * d->Cout / 4;
+        const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        DDNM_LAUNCH(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p, total4);
+    }
+    return 0;
+}

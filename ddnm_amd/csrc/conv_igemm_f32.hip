@@ -20,156 +20,7 @@
 // Epilogue: + bias + per-sample addend (temb projection) + residual, NHWC or NCHW store.
 //
 // Replaces: nn.Conv2d call sites of guided_diffusion/models.py (see include/ddnm_hip.h).
-#include "common.h"
-
-struct ConvArgs {
-    ddnm_conv_desc d;
-    int Cin, ntaps, Hs, Ws;
-    int m_tiles, n_tiles;
-    int tiles_x;        // 2-D tiling of the output image (0: flat strips, gather kernel only)
-    int TW, TW_log2;    // tile width in pixels (power of two)
-    int ksplit;         // workgroups per output tile along K (channel chunks)
-    float* ws;          // split-K slabs [ksplit][B*Ho*Wo][Cout]
-};
-
-// ---- tile geometry helper: local row r of M-tile -> output pixel
-struct TileMap {
-    int img, ty0, tx0, th_unused, TW, TW_log2, flat_base, Wo;
-    bool two_d;
-    __device__ __forceinline__ void pixel(int r, int& oy, int& ox) const {
-        if (two_d) {
-            oy = ty0 + (r >> TW_log2);
-            ox = tx0 + (r & (TW - 1));
-        } else {
-            const int pix = flat_base + r;
-            oy = pix / Wo;
-            ox = pix - oy * Wo;
-        }
-    }
-};
-
-template <int BM>
-__device__ __forceinline__ TileMap make_tilemap(const ConvArgs& p, int m_tile) {
-    TileMap t;
-    const int HWo = p.d.Ho * p.d.Wo;
-    const int per_img = HWo / BM;
-    t.img = m_tile / per_img;
-    const int t_in_img = m_tile - t.img * per_img;
-    t.TW = p.TW;
-    t.TW_log2 = p.TW_log2;
-    t.Wo = p.d.Wo;
-    t.two_d = p.tiles_x != 0;
-    if (t.two_d) {
-        const int ty = t_in_img / p.tiles_x, tx = t_in_img - ty * p.tiles_x;
-        t.ty0 = ty * (BM >> p.TW_log2);
-        t.tx0 = tx << p.TW_log2;
-        t.flat_base = 0;
-    } else {
-        t.ty0 = t.tx0 = 0;
-        t.flat_base = t_in_img * BM;
-    }
-    return t;
-}
-
-// ---- shared epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-template <int WM, int WN, int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int m_tile, int slice,
-                                              f32x16 (&acc)[MT][NT], float* lds) {
-    constexpr int BN = WN * NT * 32;
-    const ddnm_conv_desc& d = p.d;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int ncol = lane & 31, rsel = 4 * (lane >> 5);
-    const bool partial = p.ksplit > 1;
-    float* __restrict__ ws = partial ? p.ws + (size_t)slice * d.B * d.Ho * d.Wo * d.Cout : nullptr;
-    const float* __restrict__ res = d.res;
-    float* __restrict__ out = d.out;
-    const bool want_stats = d.stats_out != nullptr && !partial;
-    float cs[NT], cq[NT];              // per-lane column (= output channel) partial sum / sum of squares
-#pragma unroll
-    for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
-        if (n >= d.Cout) continue;
-        float add = 0.f;
-        if (!partial) {
-            if (d.bias) add = d.bias[n];
-            if (d.badd) add += d.badd[(size_t)tm.img * d.badd_stride + n];
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            // 32-bit element offsets (tensors here are < 2^31 elements): 16 registers instead of 32
-            unsigned o[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
-                int oy, ox;
-                tm.pixel(row, oy, ox);
-                const unsigned pix = (unsigned)((tm.img * d.Ho + oy) * d.Wo + ox);
-                if (d.res_ups && res && !partial) {
-                    o[r] = pix;                 // resolved below: two different address forms are needed
-                } else {
-                    o[r] = d.out_nchw && !partial ? (unsigned)(((tm.img * d.Cout + n) * d.Ho + oy) * d.Wo + ox)
-                                                  : pix * (unsigned)d.Cout + (unsigned)n;
-                }
-            }
-            // all 16 residual loads of this 32x32 tile are issued before the first store (a
-            // load -> add -> store chain per element would serialise 16 HBM round trips)
-            float rv[16];
-            if (res && !partial && d.res_ups) {      // residual read through a nearest x2 upsample
-                const unsigned hw = (unsigned)(d.Ho * d.Wo);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned pin = o[r] - (unsigned)tm.img * hw;
-                    const unsigned oy = pin / (unsigned)d.Wo, ox = pin - oy * (unsigned)d.Wo;
-                    rv[r] = res[(size_t)((tm.img * (d.Ho >> 1) + (int)(oy >> 1)) * (d.Wo >> 1) + (int)(ox >> 1)) * d.Cout + n];
-                    o[r] = o[r] * (unsigned)d.Cout + (unsigned)n;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = (res && !partial) ? res[o[r]] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r] + add + rv[r];
-                if (partial) ws[o[r]] = v;
-                else out[o[r]] = v;
-                cs[j] += v;
-                cq[j] += v * v;
-            }
-        }
-    }
-    // GroupNorm statistics of the tensor just produced, emitted here so the consumer's GroupNorm needs no
-    // extra pass over HBM: per (M tile, channel) fp32 partials over the tile's rows, fixed order.
-    if (want_stats) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            cs[j] += __shfl_xor(cs[j], 32);
-            cq[j] += __shfl_xor(cq[j], 32);
-        }
-        __syncthreads();                       // every wave is done with the operand tiles in LDS
-        if (lane < 32) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int c = (wn * NT + j) * 32 + lane;
-                lds[(wm * BN + c) * 2 + 0] = cs[j];
-                lds[(wm * BN + c) * 2 + 1] = cq[j];
-            }
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < BN; c += 256) {
-            const int n = n_tile * BN + c;
-            if (n < d.Cout) {
-                float a = 0.f, q = 0.f;
-#pragma unroll
-                for (int w = 0; w < WM; ++w) { a += lds[(w * BN + c) * 2]; q += lds[(w * BN + c) * 2 + 1]; }
-                d.stats_out[((size_t)m_tile * d.Cout + n) * 2 + 0] = a;
-                d.stats_out[((size_t)m_tile * d.Cout + n) * 2 + 1] = q;
-            }
-        }
-    }
-}
+#include "conv_common.h"
 
 template <int MT, int NT>
 __device__ __forceinline__ void mfma_tile_step(const float* a_frag, const float* b_frag, f32x16 (&acc)[MT][NT]) {
@@ -185,12 +36,6 @@ __device__ __forceinline__ void mfma_tile_step(const float* a_frag, const float*
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
     }
-}
-
-__device__ __forceinline__ f32x4 gn_act(f32x4 v, const f32x4 gsc, const f32x4 gsh, int silu) {
-    v = v * gsc + gsh;
-    if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-    return v;
 }
 
 // =====================================================================================
@@ -482,35 +327,6 @@ __global__ __launch_bounds__(256, 3) void conv_gather_f32_kernel(const ConvArgs 
         mfma_tile_step<MT, NT>(a_frag, b_frag, acc);
     }
     conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, As);
-}
-
-// =====================================================================================
-// split-K reduction + epilogue:  out = sum_s ws[s] + bias + badd + res   (fixed order)
-// =====================================================================================
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs p, size_t total4) {
-    const ddnm_conv_desc& d = p.d;
-    const size_t slab4 = total4;
-    const int c4n = d.Cout >> 2;
-    const size_t hw = (size_t)d.Ho * d.Wo;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        f32x4 v = reinterpret_cast<const f32x4*>(p.ws)[i];
-        for (int s = 1; s < p.ksplit; ++s) v = v + reinterpret_cast<const f32x4*>(p.ws)[i + s * slab4];
-        const int n = (int)(i % c4n) * 4;
-        const size_t pix = i / c4n;
-        const size_t b = pix / hw;
-        if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
-        if (d.badd) v = v + *reinterpret_cast<const f32x4*>(d.badd + b * d.badd_stride + n);
-        if (d.res) {
-            if (d.res_ups) {
-                const size_t p2 = pix - b * hw;
-                const size_t oy = p2 / d.Wo, ox = p2 - oy * d.Wo;
-                v = v + *reinterpret_cast<const f32x4*>(d.res + ((b * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) * d.Cout + n);
-            } else {
-                v = v + reinterpret_cast<const f32x4*>(d.res)[i];
-            }
-        }
-        reinterpret_cast<f32x4*>(d.out)[i] = v;
-    }
 }
 
 // =====================================================================================

@@ -115,6 +115,7 @@ class UNetModel:
         self.max_ch = max(L[1] for _, L in self._res_names)
         self.w = None
         self._ws = None
+        self.use_fp16 = False
 
     def _walk(self):
         for i, layers in enumerate(self.input_blocks):
@@ -131,8 +132,22 @@ class UNetModel:
         return self
 
     def convert_to_fp16(self):
-        """Accepted for drop-in compatibility (diffusion.py:145-146); this build computes in fp32."""
+        """The reference's `model.convert_to_fp16()` (diffusion.py:145-146, unet.py:619-625): the 3x3 convs
+        of the torso run on fp16 MFMA operands with fp32 accumulation (csrc/conv_igemm_f16.hip); GroupNorm,
+        softmax, embeddings, `out.*` stay fp32 exactly like fp16_util.py:15-22 leaves them."""
+        self.use_fp16 = True
+        if self.w is not None:
+            self._pack_f16()
         return self
+
+    def convert_to_fp32(self):
+        self.use_fp16 = False
+        return self
+
+    def _pack_f16(self):
+        for key in self._f16_keys:
+            if key + ".f16" not in self.w:
+                self.w[key + ".f16"] = ops.pack_conv_weight_f16(self._raw[key])
 
     def parameters(self):
         return iter(())
@@ -186,6 +201,7 @@ class UNetModel:
         dev = self.device
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731 (fp16 ckpts upcast)
         w = {}
+        self._raw, self._f16_keys = {}, []
         for k in ("time_embed.0", "time_embed.2"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
         if self.num_classes is not None:
@@ -201,8 +217,12 @@ class UNetModel:
                     for norm in ("in_layers.0", "out_layers.0"):
                         w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
                     for conv in ("in_layers.2", "out_layers.3"):
-                        w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(g(f"{n}.{conv}.weight"))
+                        raw = g(f"{n}.{conv}.weight")
+                        w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
                         w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
+                        if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
+                            self._raw[f"{n}.{conv}.weight"] = raw
+                            self._f16_keys.append(f"{n}.{conv}.weight")
                     fw.append(g(n + ".emb_layers.1.weight"))
                     fb.append(g(n + ".emb_layers.1.bias"))
                     if L[1] != L[2]:
@@ -223,7 +243,12 @@ class UNetModel:
         w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         self.w = w
         self._ws = None
+        if self.use_fp16:
+            self._pack_f16()
         return self
+
+    def _w16(self, key):
+        return self.w.get(key + ".f16") if self.use_fp16 else None
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B):
@@ -249,15 +274,18 @@ class UNetModel:
         if mode == "down":
             hp = ops.avgpool2_nhwc(x0.t, gn=gn1, silu=True)
             xs = ops.avgpool2_nhwc(x0.t)
-            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True,
+                           weight_f16=self._w16(n + ".in_layers.2.weight"))
             res_ups = False
         elif mode == "up":
             h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, gn=gn1, gn_silu=True, ups=True,
-                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True,
+                           weight_f16=self._w16(n + ".in_layers.2.weight"))
             xs, res_ups = x0, True
         else:
             h = ops.conv2d(x0, w[n + ".in_layers.2.weight"], cout, 3, src1=x1, gn=gn1, gn_silu=True,
-                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True,
+                           weight_f16=self._w16(n + ".in_layers.2.weight"))
             res_ups = False
             if cin != cout:
                 xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
@@ -267,7 +295,8 @@ class UNetModel:
                 xs = x0
         gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
         return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
-                          bias=w[n + ".out_layers.3.bias"], res=xs, res_ups=res_ups, emit_stats=True)
+                          bias=w[n + ".out_layers.3.bias"], res=xs, res_ups=res_ups, emit_stats=True,
+                          weight_f16=self._w16(n + ".out_layers.3.weight"))
 
     def _attn(self, n, x):
         w = self.w

@@ -94,9 +94,14 @@ class Act:
         self.t, self.stats, self.tiles = t, stats, tiles
 
 
+def pack_conv_weight_f16(w):
+    """OIHW fp32/fp16 -> (O, ky, kx, I) IEEE fp16, Cout padded to 128 (operands of ddnm_conv3x3_f16_f32)."""
+    return pack_conv_weight(w).to(torch.float16).contiguous()
+
+
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
-           emit_stats=False):
+           emit_stats=False, weight_f16=None):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
     With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them)."""
     src0 = src0.t if isinstance(src0, Act) else src0
@@ -123,25 +128,37 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
     d.badd_stride, d.tile, d.res_ups = badd_stride, tile, int(res_ups)
+    L = _lib.lib()
+    # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
+    # shape qualifies; everything else runs the exact-fp32 kernels
+    f16 = weight_f16 is not None and L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
+    if f16:
+        d.weight = weight_f16.data_ptr()
+    fn_run = L.ddnm_conv3x3_f16_f32 if f16 else L.ddnm_conv2d_f32
+    fn_tiles = L.ddnm_conv3x3_f16_stats_tiles if f16 else L.ddnm_conv2d_f32_stats_tiles
+    fn_ws = L.ddnm_conv3x3_f16_workspace_floats if f16 else L.ddnm_conv2d_f32_workspace_floats
     stats, tiles = None, 0
     if emit_stats and not _NO_FUSED_GN:
-        tiles = _lib.lib().ddnm_conv2d_f32_stats_tiles(ctypes.byref(d))
+        tiles = fn_tiles(ctypes.byref(d))
         if tiles > 0:
             stats = torch.empty(B * tiles * cout * 2, dtype=torch.float32, device=src0.device)
             d.stats_out = stats.data_ptr()
-    need = _lib.lib().ddnm_conv2d_f32_workspace_floats(ctypes.byref(d))
+    need = fn_ws(ctypes.byref(d))
     if need > 0:
         ws = _conv_workspace(src0.device, need)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
     if _timer is None:
-        check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+        check(fn_run(ctypes.byref(d), _stream()), "ddnm_conv2d")
     else:
-        tn = _lib.lib().ddnm_conv2d_f32_tile_n(ctypes.byref(d))
-        kind = "conv3x3_halo_f32" if (ksize == 3 and stride == 1) else "conv_gather_f32"
-        variant = kind + {128: "<128x128>", 64: "<64x64>", 32: "<128x32>"}[tn]
+        if f16:
+            variant = "conv3x3_halo_f16<256x128>"
+        else:
+            tn = L.ddnm_conv2d_f32_tile_n(ctypes.byref(d))
+            kind = "conv3x3_halo_f32" if (ksize == 3 and stride == 1) else "conv_gather_f32"
+            variant = kind + {128: "<128x128>", 64: "<64x64>", 32: "<128x32>"}[tn]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.lib().ddnm_conv2d_f32(ctypes.byref(d), _stream()), "ddnm_conv2d_f32")
+        check(fn_run(ctypes.byref(d), _stream()), "ddnm_conv2d")
         e1.record()
         _timer.records.append((variant, 2.0 * B * Ho * Wo * cout * ksize * ksize * (C0 + C1), e0, e1))
     if emit_stats:

@@ -87,6 +87,16 @@ int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d);
 /* M tiles per image of the auto plan if this launch can emit `stats_out` (0: split-K or NCHW launch). */
 int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d);
 
+/* 3x3 / stride 1 / pad 1 convolution with fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate:
+ * the reference's `use_fp16` torso (guided_diffusion/unet.py:619-625, fp16_util.py:15-22).  Same descriptor;
+ * `weight` points to the (O,ky,kx,I)-packed weights stored as IEEE fp16, activations / bias / residual /
+ * output stay fp32 in HBM (rounded to fp16 while the halo tile is staged).  Needs Cin % 64 == 0,
+ * Cout % 128 == 0, Ho*Wo % 256 == 0; `_supported` tells whether a desc qualifies (else use ddnm_conv2d_f32). */
+int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream);
+int ddnm_conv3x3_f16_supported(const ddnm_conv_desc* d);
+int64_t ddnm_conv3x3_f16_workspace_floats(const ddnm_conv_desc* d);
+int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d);
+
 /* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
  * Replaces torch.nn.GroupNorm(32, C, eps) (models.py:32-33; guided_diffusion/nn.py:17-19).

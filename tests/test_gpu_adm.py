@@ -89,3 +89,60 @@ def test_adm_sampler_vs_reference_golden(hip, name, golden_dir):
     g = np.load(f"{golden_dir}/adm_forward.npz")
     assert rel(xs[0], torch.from_numpy(g[f"mid_{name}_x"])) < 2e-4
     assert rel(x0s[0], torch.from_numpy(g[f"mid_{name}_x0"])) < 2e-4
+
+
+# ------------------------------------------------------------------ fp16-operand MFMA path (use_fp16 torso)
+@pytest.mark.parametrize("B,C0,C1,Cout,H,gn,res,ups", [(1, 256, 0, 256, 32, True, True, False),
+                                                       (2, 256, 256, 256, 16, True, False, False),
+                                                       (1, 128, 0, 128, 64, False, True, False),
+                                                       (1, 256, 0, 256, 16, True, True, True),
+                                                       (4, 512, 0, 512, 16, True, True, False)])
+def test_conv3x3_f16_operands(hip, B, C0, C1, Cout, H, gn, res, ups):
+    """fp16 MFMA operands, fp32 accumulate.  Checked two ways: (a) against an fp32 convolution of the
+    fp16-ROUNDED operands (isolates the kernel: only accumulation order differs, tol 2e-5), (b) against
+    the unrounded fp32 convolution (the precision contract: fp16-class error, tol 2e-3)."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(11)
+    Cin = C0 + C1
+    a = torch.randn(B, C0, H, H, generator=g)
+    b = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.randn(B, Cin, generator=g), torch.randn(B, Cin, generator=g)
+    Ho = 2 * H if ups else H
+    r = torch.randn(B, Cout, Ho, Ho, generator=g) if res else None
+    x = a if b is None else torch.cat([a, b], 1)
+    act = x
+    if gn:
+        act = x * sc[:, :, None, None] + sh[:, :, None, None]
+        act = act * torch.sigmoid(act)
+    if ups:
+        act = F.interpolate(act, scale_factor=2.0, mode="nearest")
+    ref32 = F.conv2d(act, w, bias, padding=1) + (r if res else 0)
+    ref16 = F.conv2d(act.half().float(), w.half().float(), bias, padding=1) + (r if res else 0)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()       # noqa: E731
+    out = ops.conv2d(nh(a), ops.pack_conv_weight(w.cuda()), Cout, 3, src1=None if b is None else nh(b), bias=bias.cuda(),
+                     gn=(sc.cuda().contiguous(), sh.cuda().contiguous()) if gn else None, gn_silu=True,
+                     res=nh(r) if res else None, ups=ups, emit_stats=True, weight_f16=ops.pack_conv_weight_f16(w.cuda()))
+    torch.cuda.synchronize()
+    got = out.t.cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref16) < 2e-5
+    assert rel(got, ref32) < 2e-3
+
+
+@pytest.mark.parametrize("kind,batch", [("mid", 2), ("full", 1)])
+def test_adm_forward_fp16_torso(hip, kind, batch, golden_dir):
+    """`convert_to_fp16()` engine vs the fp32 goldens of the reference: single-forward rel-L2 <= 3e-3
+    (SURVEY.md section 8c bar for half-precision kernels; reference fp16 vs fp32 itself: 1.4e-3)."""
+    from oracle import cases
+    cfg, sd = cases.adm_net(kind)
+    x, t, y = cases.adm_forward_inputs(cfg, batch)
+    m = build(cfg, sd)
+    m.convert_to_fp16()
+    e = (m(x.cuda(), t.cuda(), y.cuda()) if y is not None else m(x.cuda(), t.cuda())).cpu()
+    g = np.load(f"{golden_dir}/adm_forward.npz")
+    ref = torch.from_numpy(g[f"{kind}_eps"])
+    got = e if kind != "full" else e[..., ::4, ::4]
+    err = rel(got, ref)
+    assert 1e-7 < err < 3e-3, err            # > 1e-7: the fp16 path really ran
