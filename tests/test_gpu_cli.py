@@ -1,0 +1,94 @@
+"""The drop-in shell on the GPU: reference command lines through main.py / Diffusion, and the
+simplified (--simplified) loop against its oracle restatement."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _reduced_yaml(tmp_path, T=5, batch=2):
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "celeba_hq.yml")))
+    cfg["time_travel"]["T_sampling"] = T
+    cfg["sampling"]["batch_size"] = batch
+    cfg["data"]["image_size"] = 64
+    cfg["model"]["ch_mult"] = [1, 1, 2]
+    os.makedirs(tmp_path / "configs", exist_ok=True)
+    with open(tmp_path / "configs" / "mini.yml", "w") as f:
+        yaml.safe_dump(cfg, f)
+
+
+@pytest.mark.parametrize("deg,scale", [("sr_bicubic", "4"), ("colorization", "0"), ("cs_walshhadamard", "0.25")])
+def test_main_cli_end_to_end(hip, tmp_path, monkeypatch, deg, scale, capsys):
+    """`python main.py --ni --config ... --deg ... -i ...` (evaluation.sh style) on synthetic images with
+    seeded random weights: images are written, PSNR is reported, exit code 0."""
+    import main
+    _reduced_yaml(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DDNM_RANDOM_WEIGHTS", "1")
+    rc = main.main(["--ni", "--config", "mini.yml", "--path_y", "synthetic:4", "--eta", "0.85", "--deg", deg,
+                    "--deg_scale", scale, "--sigma_y", "0.", "-i", "out_" + deg])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Total Average PSNR" in out and "Number of samples: 4" in out, out
+    folder = tmp_path / "exp" / "image_samples" / ("out_" + deg)
+    pngs = sorted(p.name for p in folder.glob("*.png"))
+    assert pngs == ["0_0.png", "1_0.png", "2_0.png", "3_0.png"]
+    assert len(list((folder / "Apy").glob("*.png"))) == 8
+
+
+def test_main_cli_reports_errors_but_returns_zero(hip, tmp_path, monkeypatch, caplog):
+    import main
+    _reduced_yaml(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DDNM_RANDOM_WEIGHTS", "1")
+    rc = main.main(["--ni", "--config", "mini.yml", "--path_y", "synthetic:1", "--deg", "deblur_nope", "-i", "bad"])
+    assert rc == 0          # reference main.py:164-170 swallows the ValueError("degradation type not supported")
+
+
+@pytest.mark.parametrize("deg", ["sr_averagepooling", "colorization", "inpainting", "denoising"])
+@pytest.mark.parametrize("sigma_y", [0.0, 0.3])
+def test_simplified_loop_vs_oracle(hip, deg, sigma_y, golden_dir, tmp_path, monkeypatch):
+    """guided_diffusion/diffusion.py:333-397 (Eq. 19 lambda_t / gamma_t, sigma_t = sqrt(1 - abar'^2))."""
+    from ddnm_amd.guided_diffusion.diffusion import simplified_loop
+    from ddnm_amd.guided_diffusion.models import Model
+    from ddnm_amd.functions import svd_operators as E
+    from oracle import cases, sampler, unet_celeba, schedule
+    cfg, sd = cases.celeba_net("small")
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 10, 2, 2
+    n_it = len(schedule.jump_times(10, 2, 2)) - 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 1, n_it)
+    d = cfg.data.image_size
+    mask = cases.random_mask(d)
+    if deg == "sr_averagepooling":
+        A = torch.nn.AdaptiveAvgPool2d((d // 4, d // 4))
+        Ap = lambda z: sampler.mean_upsample(z, 4)                         # noqa: E731
+        op = E.SuperResolution(3, d, 4, "cuda")
+    elif deg == "colorization":
+        A = lambda z: (z[:, 0] / 3 + z[:, 1] / 3 + z[:, 2] / 3)[:, None].repeat(1, 3, 1, 1)     # noqa: E731  color2gray
+        Ap = lambda z: torch.stack([z[:, 0] * (1 / 3) / (3 * (1 / 3) ** 2)] * 3, 1)            # noqa: E731  gray2color
+        op = E.Colorization(d, "cuda", weights=(1 / 3, 1 / 3, 1 / 3))
+    elif deg == "inpainting":
+        A = Ap = lambda z: z * mask                                                              # noqa: E731
+        r = torch.nonzero(mask.reshape(-1) == 0).long().reshape(-1) * 3
+        op = E.Inpainting(3, d, torch.cat([r, r + 1, r + 2], 0), "cuda")
+    else:
+        A = Ap = lambda z: z                                                                     # noqa: E731
+        op = E.Denoising(3, d, "cuda")
+    y_img = A(x_orig)
+    ref, _ = sampler.simplified_ddnm(x_T.clone(), unet_celeba.Net(sd, cfg), cases.betas(), 0.85, A, Ap, y_img, sigma_y,
+                                     tape, T_sampling=10, travel_length=2, travel_repeat=2)
+    model = Model(cfg)
+    model.load_state_dict(sd)
+    y_eng = op.A(x_orig.cuda())          # same measurement in the engine operator's own layout
+    got = simplified_loop(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y_eng, sigma_y, cfg,
+                          noise=[n.cuda() for n in tape])
+    torch.cuda.synchronize()
+    assert rel(got, ref) < 2e-4
