@@ -52,7 +52,7 @@ __device__ __forceinline__ TileMap make_tilemap(const ConvArgs& p, int m_tile) {
 }
 
 // ---- shared epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, bool RES_ALL_UPFRONT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int m_tile, int slice,
                                               f32x16 (&acc)[MT][NT], float* lds) {
     constexpr int BN = WN * NT * 32;
@@ -68,6 +68,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
     float cs[NT], cq[NT];              // per-lane column (= output channel) partial sum / sum of squares
 #pragma unroll
     for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+    if (RES_ALL_UPFRONT && d.Cout % BN == 0 && !d.out_nchw) {
+        // One workgroup per CU (fp16 kernel): nothing else hides the residual round trip, so ALL residual
+        // loads of the wave's MT x NT tiles are issued before the first add/store (one latency, not MT*NT).
+        unsigned o[MT][NT][16];
+        float rv[MT][NT][16];
+        const bool use_res = res && !partial;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + rsel;
+                int oy, ox;
+                tm.pixel(row, oy, ox);
+                const unsigned pix = (unsigned)((tm.img * d.Ho + oy) * d.Wo + ox);
+                const unsigned rpix = d.res_ups ? (unsigned)((tm.img * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) : pix;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const unsigned n = (unsigned)(n_tile * BN + (wn * NT + j) * 32 + ncol);
+                    o[i][j][r] = pix * (unsigned)d.Cout + n;
+                    rv[i][j][r] = use_res ? res[(size_t)rpix * d.Cout + n] : 0.f;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
+            float add = 0.f;
+            if (!partial) {
+                if (d.bias) add = d.bias[n];
+                if (d.badd) add += d.badd[(size_t)tm.img * d.badd_stride + n];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + add + rv[i][j][r];
+                    if (partial) ws[o[i][j][r]] = v;
+                    else out[o[i][j][r]] = v;
+                    cs[j] += v;
+                    cq[j] += v * v;
+                }
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n_tile * BN + (wn * NT + j) * 32 + ncol;
@@ -119,6 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
                 cq[j] += v * v;
             }
         }
+    }
     }
     // GroupNorm statistics of the tensor just produced, emitted here so the consumer's GroupNorm needs no
     // extra pass over HBM: per (M tile, channel) fp32 partials over the tile's rows, fixed order.

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             }
         }
     }
-    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
+    conv_epilogue<WM, WN, MT, NT, true>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
