@@ -101,11 +101,85 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
                                       f"threads ({avail} logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}"}
 
 
+def bench_adm(args, ddist, rank, world, dev):
+    """Informational ImageNet workloads (BASELINE configs[2], configs[3] per-GPU shards): ADM UNet
+    (552.81 M params, 2242.87 GFLOP per forward per image), fp16-operand MFMA torso."""
+    import types
+    from ddnm_amd.functions.svd_ddnm import ddnm_diffusion, get_schedule_jump
+    from ddnm_amd.functions.svd_operators import Colorization, Inpainting
+    from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
+    from ddnm_amd.guided_diffusion.unet import create_model
+    ns = types.SimpleNamespace
+    travel = (10, 3) if args.workload == "c4" else (1, 1)
+    cfg = ns(diffusion=ns(num_diffusion_timesteps=1000), data=ns(image_size=256, channels=3),
+             time_travel=ns(T_sampling=T_SAMPLING, travel_length=travel[0], travel_repeat=travel[1]))
+    model = create_model(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8",
+                         num_head_channels=64, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
+                         use_fp16=True)
+    model.device = dev
+    model.load_state_dict(model.random_state_dict(1234))
+    model.convert_to_fp16()
+    betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
+                                               num_diffusion_timesteps=1000)).float().to(dev)
+    B = 4
+    g = torch.Generator().manual_seed(1234 + rank)
+    x_orig = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
+    if args.workload == "c3":
+        op = Colorization(256, dev)
+    else:
+        mask = (torch.rand(256, 256, generator=g) > 0.26).long().reshape(-1)        # 74 % kept, like exp/inp_masks/mask.npy
+        r = torch.nonzero(mask == 0).long().reshape(-1) * 3
+        op = Inpainting(3, 256, torch.cat([r, r + 1, r + 2], 0), dev)
+    y = op.A(x_orig)
+    times = get_schedule_jump(T_SAMPLING, *travel)
+    nfe = sum(1 for a, b in zip(times[:-1], times[1:]) if b < a)
+
+    def one_pass():
+        x_T = torch.randn(B, 3, 256, 256, device=dev)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg)
+        return ddist.gather_images(xs[0])
+
+    for _ in range(args.warmup):
+        out = one_pass()
+    ddist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    torch.cuda.synchronize()
+    ddist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = tmax.item()
+    value = args.steps * B * world / dt
+    tfl = value * nfe * 2242.87e9 / 1e12 / world
+    line = {"metric": "restored images/sec @256x256, 100 DDIM steps", "value": round(value, 4), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands / f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": {"c3": "imagenet_256.yml colorization, T_sampling=100, batch 4 per GPU (BASELINE configs[2] shard)",
+                                    "c4": "imagenet_256.yml inpainting, time-travel l=10 r=3 (280 NFE + 180 re-noise), "
+                                          "batch 4 per GPU (BASELINE configs[3] shard)"}[args.workload],
+                       "global_batch": B * world, "nfe_per_image": nfe},
+            "whole_loop_tflops_per_gpu": round(tfl, 1), "finite": bool(torch.isfinite(out).all())}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        ddist.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2 (default, headline): celeba_hq sr_bicubic 4x B=8/GPU, fp32.  Informational extras: "
+                         "c3 = imagenet_256 colorization B=4/GPU, c4 = imagenet_256 inpainting with time travel "
+                         "l=10 r=3 B=4/GPU (ADM UNet, fp16-operand torso like the reference's use_fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -124,6 +198,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     cfg = make_config()
+    if args.workload != "c2":
+        return bench_adm(args, ddist, rank, world, dev)
     model = Model(cfg, device=dev)
     sd = model.random_state_dict(seed=1234)          # identical replica on every rank, no broadcast
     model.load_state_dict(sd)
