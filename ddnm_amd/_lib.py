@@ -88,6 +88,12 @@ PROTOTYPES = {
                                         c_void_p, c_void_p, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
     "ddnm_step_denoise_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int32, c_int64, POINTER(StepScalars), c_void_p]),
+    "ddnm_axpby_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ddnm_mask_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_float, c_float,
+                                    c_float, c_float, c_void_p]),
+    "ddnm_site_spectral_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                         c_int32, c_int32, c_void_p, c_int32, c_float, c_float, c_float, c_float,
+                                         c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_op_upsample_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

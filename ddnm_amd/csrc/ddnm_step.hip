@@ -419,3 +419,101 @@ extern "C" int ddnm_finalize_psnr_f32(const float* x, const float* x_orig, float
     DDNM_LAUNCH(finalize_psnr_kernel, dim3(64, B), dim3(256), 0, st, x, x_orig, img, sse, chw);
     return 0;
 }
+
+// ================================================================ DDNM+ (sigma_y > 0) building blocks
+// functions/svd_ddnm.py:80-164 with the per-operator Lambda / Lambda_noise of functions/svd_operators.py.
+
+// out = a*x + b*y   (y may be NULL)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                    float* __restrict__ out, int64_t n, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = y ? x[i] * a + y[i] * b : x[i] * a;
+}
+
+extern "C" int ddnm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream) {
+    if (!x || !out || n <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(axpby_kernel, GRID_1D(n), dim3(256), 0, (hipStream_t)stream, x, y, out, n, a, b);
+    return 0;
+}
+
+// out = (m ? cx_m : cx_n) * x + (m ? cy_m : cy_n) * y, m = mask[(plane % planes_mask)][p] != 0 (NULL mask: measured
+// everywhere).  Lambda / Lambda_noise of Inpainting (svd_operators.py:361-439) and the spectral weighting of
+// WalshHadamardCS (:253-320) are this, with the kept-pixel mask / the permuted measurement mask.
+__global__ __launch_bounds__(256) void mask_mix_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ mask, int planes_mask,
+                                                       int64_t plane_elems, float* __restrict__ out, int64_t total,
+                                                       float cx_m, float cx_n, float cy_m, float cy_n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        bool m = true;
+        if (mask) {
+            const int64_t plane = i / plane_elems, p = i - plane * plane_elems;
+            m = mask[(plane % planes_mask) * plane_elems + p] != 0.f;
+        }
+        float v = x[i] * (m ? cx_m : cx_n);
+        if (y) v = v + y[i] * (m ? cy_m : cy_n);
+        out[i] = v;
+    }
+}
+
+extern "C" int ddnm_mask_mix_f32(const float* x, const float* y, const float* mask, int32_t planes_mask,
+                                 int64_t plane_elems, float* out, int64_t total, float cx_m, float cx_n, float cy_m,
+                                 float cy_n, void* stream) {
+    if (!x || !out || total <= 0 || plane_elems <= 0 || (mask && planes_mask <= 0)) return DDNM_E_BADARG;
+    DDNM_LAUNCH(mask_mix_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, mask, planes_mask,
+                plane_elems, out, total, cx_m, cx_n, cy_m, cy_n);
+    return 0;
+}
+
+// Per-site spectral operations with the small orthogonal V of a 1 x n measurement row (n = r*r for
+// SuperResolution patches, n = 3 for Colorization needles); spectral index 0 is the measured direction.
+//   op 0 (Lambda,        :535-571, :669-695): out = x + (lam_m - 1) * V[:,0] * (V[:,0] . x)
+//   op 1 (Lambda_noise,  :573-623, :697-736): out = V (d1 .* x~ + d2 .* y~),  x~/y~ = RAW site entries
+// mode 0: site = r x r spatial patch of one channel plane [BC][H][W]; mode 1: site = the 3 channels of a pixel.
+__global__ __launch_bounds__(256) void site_spectral_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ V, int n, int mode, int r,
+                                                            int H, int W, int64_t HW, float* __restrict__ out,
+                                                            int64_t total, int op, float c0, float c1, float c2,
+                                                            float c3) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        // element e -> (site base offset, index i inside the site, stride pattern)
+        int64_t base;
+        int i;
+        if (mode == 0) {
+            const int64_t plane = e / HW, p = e - plane * HW;
+            const int yy = (int)(p / W), xx = (int)(p - (int64_t)yy * W);
+            base = plane * HW + (int64_t)(yy / r * r) * W + (xx / r * r);
+            i = (yy % r) * r + (xx % r);
+        } else {
+            const int64_t b = e / (3 * HW), q = e - b * 3 * HW;
+            i = (int)(q / HW);
+            base = b * 3 * HW + (q - (int64_t)i * HW);
+        }
+        auto at = [&](int k) -> int64_t { return mode == 0 ? base + (int64_t)(k / r) * W + (k % r) : base + (int64_t)k * HW; };
+        float acc = 0.f;
+        if (op == 0) {
+            float dot = 0.f;
+            for (int k = 0; k < n; ++k) dot += V[k * n] * x[at(k)];
+            acc = x[e] + (c0 - 1.0f) * V[i * n] * dot;
+        } else {
+            for (int k = 0; k < n; ++k) {
+                float z = x[at(k)] * (k == 0 ? c0 : c1);
+                if (y) z += y[at(k)] * (k == 0 ? c2 : c3);
+                acc += V[i * n + k] * z;
+            }
+        }
+        out[e] = acc;
+    }
+}
+
+extern "C" int ddnm_site_spectral_f32(const float* x, const float* y, const float* V, int32_t n, int32_t mode,
+                                      int32_t r, int32_t B, int32_t C, int32_t H, int32_t W, float* out, int32_t op,
+                                      float c0, float c1, float c2, float c3, void* stream) {
+    if (!x || !V || !out || n <= 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DDNM_E_BADARG;
+    if (mode == 0 && (r <= 0 || n != r * r || H % r || W % r)) return DDNM_E_SHAPE;
+    if (mode == 1 && (n != 3 || C != 3)) return DDNM_E_SHAPE;
+    if (mode != 0 && mode != 1) return DDNM_E_BADARG;
+    const int64_t total = (int64_t)B * C * H * W;
+    DDNM_LAUNCH(site_spectral_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, V, n, mode, r, H, W,
+                (int64_t)H * W, out, total, op, c0, c1, c2, c3);
+    return 0;
+}

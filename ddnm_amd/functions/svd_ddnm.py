@@ -132,3 +132,62 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                 ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
     return [xt], [x0_t]
+
+
+def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, classes=None, config=None, noise=None):
+    """DDNM+ for noisy measurements: drop-in for `functions/svd_ddnm.py::ddnm_plus_diffusion` (:80-164).
+
+      x0|t  = (x_t - eps*sqrt(1-abar_t)) / sqrt(abar_t)                                  (Eq. 12)
+      x0^   = x0|t - Lambda( A^+ (A x0|t - y) )                                          (Eq. 17)
+      x_t-1 = sqrt(abar') x0^ + Lambda_noise( N(0,I), eps )                              (Eq. 51)
+
+    with the operator's `Lambda` / `Lambda_noise` (spectral lambda_t and noise mixing).  Every product is a
+    HIP kernel; per step: UNet forward, x0 kernel, A / A^+ kernels, Lambda, Lambda_noise, combine."""
+    if not x.is_cuda:
+        raise RuntimeError("ddnm_amd.ddnm_plus_diffusion runs on the GPU only (no CPU fallback)")
+    skip = config.diffusion.num_diffusion_timesteps // config.time_travel.T_sampling
+    n = x.size(0)
+    times = get_schedule_jump(config.time_travel.T_sampling, config.time_travel.travel_length,
+                              config.time_travel.travel_repeat)
+    alpha = _AlphaTable(b)
+    x = x.float().contiguous()
+    y = y.reshape(n, -1).float().contiguous()
+    draw = _noise_source(noise, x)
+    from .svd_operators import _axpby
+    xt = x
+    x0_t = torch.empty_like(x)
+    bufs = [torch.empty_like(x), torch.empty_like(x)]
+    have_x0 = False
+    with torch.no_grad():
+        for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
+            i, j = i * skip, j * skip
+            if j < 0:
+                j = -1
+            at_next = alpha(j)
+            out = bufs[k & 1]
+            if j < i:
+                at = alpha(i)
+                t = torch.full((n,), float(i), device=x.device, dtype=torch.float32)
+                if cls_fn is None:
+                    et = model(xt, t)
+                else:
+                    cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
+                    et = model(xt, t, cls)
+                    et = et[:, :3]
+                    et = (et - (1 - at).sqrt() * cls_fn(x, t, cls)).contiguous()
+                if et.size(1) == 6:
+                    et = et[:, :3].contiguous()
+                a, sigma_t = at_next.sqrt(), (1 - at_next).sqrt()
+                s = ops.step_scalars(at, at_next, eta)
+                ops.step_x0(xt, et, s, out=x0_t)
+                resid = _axpby(A_funcs.A(x0_t), y, 1.0, -1.0)
+                corr = A_funcs.Lambda(A_funcs.A_pinv(resid), a, sigma_y, sigma_t, eta).reshape(x.shape)
+                nz = A_funcs.Lambda_noise(draw(k), a, sigma_y, sigma_t, eta, et).reshape(x.shape)
+                s.c1, s.c2, s.lam = 1.0, 0.0, 1.0        # x_t-1 = sqrt(abar') (x0 - corr) + 1 * nz
+                ops.step_combine(x0_t, corr, None, nz, et, s, out=out)
+                have_x0 = True
+            else:
+                assert have_x0
+                ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
+            xt = out
+    return [xt], [x0_t]

@@ -18,8 +18,10 @@ Every class also implements `ddnm_step(...)`, the fused x0 / projection / DDIM
 update of one sampler step (functions/svd_ddnm.py:57-65) that `ddnm_diffusion`
 uses when it is handed one of these objects.
 
-`Lambda` / `Lambda_noise` (the sigma_y > 0 path) are
-not built yet and raise NotImplementedError like the reference does for SRConv.
+`Lambda` / `Lambda_noise` (the sigma_y > 0 path of `ddnm_plus_diffusion`) follow the reference's
+per-class definitions, including its quirk of feeding the RAW patch / needle / permuted entries of
+the noise and of eps to `V` in `Lambda_noise`; `SRConv` has none and raises NotImplementedError
+like the reference.
 """
 import ctypes
 
@@ -39,6 +41,58 @@ def _img(vec, c, d):
     if v.dtype != torch.float32 or not v.is_contiguous():
         v = v.float().contiguous()
     return v
+
+
+def spectral_coefficients(s, a, sigma_y, sigma_t, eta):
+    """(lambda, d1, d2) of one singular value `s` (0 = null space) -- the per-entry rules that every
+    `Lambda` / `Lambda_noise` of the reference spells out with change_index masks (e.g. svd_operators.py:548-605):
+      lambda = s*sigma_t*sqrt(1-eta^2)/(a*sigma_y) where sigma_t < a*sigma_y/s, else 1;
+      (d1, d2) = (sigma_t*eta, 0) below that threshold, (sqrt(sigma_t^2 - a^2 sigma_y^2/s^2), 0) above it,
+      (sigma_t*eta, sigma_t*sqrt(1-eta^2)) for s = 0."""
+    a, sigma_y, sigma_t = float(a), float(sigma_y), float(sigma_t)
+    c1, c2 = sigma_t * eta, sigma_t * (1 - eta ** 2) ** 0.5
+    if s == 0 or a == 0 or sigma_y == 0:
+        return 1.0, c1, c2
+    thr = a * sigma_y / s
+    if sigma_t < thr:
+        return s * sigma_t * (1 - eta ** 2) ** 0.5 / a / sigma_y, c1, 0.0
+    if sigma_t > thr:
+        return 1.0, (sigma_t ** 2 - a ** 2 * sigma_y ** 2 / s ** 2) ** 0.5, 0.0
+    return 1.0, c1, c2
+
+
+def _flat(vec):
+    v = vec.reshape(vec.shape[0], -1)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    return v
+
+
+def _axpby(x, y, a, b):
+    out = torch.empty_like(x)
+    check(_lib.lib().ddnm_axpby_f32(_p(x), _p(y), _p(out), x.numel(), a, b, ops._stream()), "ddnm_axpby_f32")
+    return out
+
+
+def _mask_mix(x, y, mask, planes_mask, plane_elems, cx_m, cx_n, cy_m=0.0, cy_n=0.0):
+    out = torch.empty_like(x)
+    check(_lib.lib().ddnm_mask_mix_f32(_p(x), _p(y), _p(mask), planes_mask, plane_elems, _p(out), x.numel(), cx_m, cx_n,
+                                       cy_m, cy_n, ops._stream()), "ddnm_mask_mix_f32")
+    return out
+
+
+def _site_spectral(x, y, V, n, mode, r, B, C, H, W, op, c0, c1=0.0, c2=0.0, c3=0.0):
+    out = torch.empty_like(x)
+    check(_lib.lib().ddnm_site_spectral_f32(_p(x), _p(y), _p(V), n, mode, r, B, C, H, W, _p(out), op, c0, c1, c2, c3,
+                                            ops._stream()), "ddnm_site_spectral_f32")
+    return out
+
+
+def _row_svd(row, device):
+    """sigma and V of a 1 x n measurement row via torch.svd on the host, like the reference's constructors
+    (svd_operators.py:487,633); the null-space columns of V are LAPACK's choice and are part of the contract."""
+    U, S, V = torch.svd(torch.tensor([row], dtype=torch.float32), some=False)
+    return float(S[0]), V.contiguous().to(device)
 
 
 class A_functions:
@@ -67,7 +121,7 @@ class A_functions:
         """Generic step: x0, proj = A^+(A x0 - y), combine.  Subclasses fuse it."""
         B = xt.shape[0]
         ops.step_x0(xt, et, s, out=x0_out)
-        resid = self.A(x0_out) - y.reshape(B, -1)          # tiny elementwise; overridden where it matters
+        resid = _axpby(self.A(x0_out), _flat(y), 1.0, -1.0)
         proj = self.A_pinv(resid).reshape(xt.shape)
         ops.step_combine(x0_out, proj, None, noise, et, s, out=xt_next)
 
@@ -84,6 +138,16 @@ class Denoising(A_functions):
 
     def singulars(self):
         return torch.ones(self.channels * self.img_dim ** 2, device=self.device)
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:464-469
+        if float(sigma_t) < float(a) * sigma_y:
+            return _axpby(_flat(vec), None, float(sigma_t) * (1 - eta ** 2) ** 0.5 / float(a) / sigma_y, 0.0)
+        return _flat(vec)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :471-476 (epsilon is ignored there)
+        a, sigma_t = float(a), float(sigma_t)
+        f = (sigma_t ** 2 - a ** 2 * sigma_y ** 2) ** 0.5 if sigma_t >= a * sigma_y else sigma_t * eta
+        return _axpby(_flat(vec), None, f, 0.0)
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         B = xt.shape[0]
@@ -117,6 +181,26 @@ class SuperResolution(A_functions):
 
     def singulars(self):
         return torch.full((self.channels * self.y_dim ** 2,), 1.0 / self.ratio, device=self.device)
+
+    def _svd(self):
+        if not hasattr(self, "_V"):
+            self._s, self._V = _row_svd([1 / self.ratio ** 2] * self.ratio ** 2, self.device)
+        return self._s, self._V
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:535-571
+        s, V = self._svd()
+        lam = spectral_coefficients(s, a, sigma_y, sigma_t, eta)[0]
+        v = _flat(vec)
+        return _site_spectral(v, None, V, self.ratio ** 2, 0, self.ratio, v.shape[0], self.channels, self.img_dim,
+                              self.img_dim, 0, lam)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :573-623
+        s, V = self._svd()
+        _, d1m, d2m = spectral_coefficients(s, a, sigma_y, sigma_t, eta)
+        _, d1n, d2n = spectral_coefficients(0.0, a, sigma_y, sigma_t, eta)
+        v = _flat(vec)
+        return _site_spectral(v, _flat(epsilon), V, self.ratio ** 2, 0, self.ratio, v.shape[0], self.channels,
+                              self.img_dim, self.img_dim, 1, d1m, d1n, d2m, d2n)
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         if self.ratio != 4 or self.channels != 3:
@@ -153,6 +237,26 @@ class Colorization(A_functions):
         w = torch.tensor([0.3333, 0.3334, 0.3333] if self._w is None else list(self._w))
         return torch.full((self.img_dim ** 2,), float((w * w).sum().sqrt()), device=self.device)
 
+    def _svd(self):
+        if not hasattr(self, "_V"):
+            row = [0.3333, 0.3334, 0.3333] if self._w is None else [float(v) for v in self._w]
+            self._s, self._V = _row_svd(row, self.device)
+        return self._s, self._V
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:669-695
+        s, V = self._svd()
+        lam = spectral_coefficients(s, a, sigma_y, sigma_t, eta)[0]
+        v = _flat(vec)
+        return _site_spectral(v, None, V, 3, 1, 1, v.shape[0], 3, self.img_dim, self.img_dim, 0, lam)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :697-736
+        s, V = self._svd()
+        _, d1m, d2m = spectral_coefficients(s, a, sigma_y, sigma_t, eta)
+        _, d1n, d2n = spectral_coefficients(0.0, a, sigma_y, sigma_t, eta)
+        v = _flat(vec)
+        return _site_spectral(v, _flat(epsilon), V, 3, 1, 1, v.shape[0], 3, self.img_dim, self.img_dim, 1, d1m, d1n,
+                              d2m, d2n)
+
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         B = xt.shape[0]
         ep, es = ops._et_args(et)
@@ -179,6 +283,7 @@ class Inpainting(A_functions):
         rank[~keep] = -1
         self.n_kept = int(keep.sum())
         self.rank = rank.to(torch.int32).to(device).contiguous()
+        self.kept_mask = keep.float().to(device).contiguous()            # [HW], shared by the 3 channel planes
         self.missing_indices = missing_indices
 
     def A(self, vec):
@@ -199,6 +304,15 @@ class Inpainting(A_functions):
 
     def singulars(self):
         return torch.ones(3 * self.n_kept, device=self.device)
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:361-387
+        lam = spectral_coefficients(1.0, a, sigma_y, sigma_t, eta)[0]
+        return _mask_mix(_flat(vec), None, self.kept_mask, 1, self.img_dim ** 2, lam, 1.0)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :389-439
+        _, d1m, d2m = spectral_coefficients(1.0, a, sigma_y, sigma_t, eta)
+        _, d1n, d2n = spectral_coefficients(0.0, a, sigma_y, sigma_t, eta)
+        return _mask_mix(_flat(vec), _flat(epsilon), self.kept_mask, 1, self.img_dim ** 2, d1m, d1n, d2m, d2n)
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         B = xt.shape[0]
@@ -255,6 +369,25 @@ class WalshHadamardCS(A_functions):
 
     def singulars(self):
         return torch.ones(self.n_keep, device=self.device)
+
+    def _fwht(self, planes):
+        out = torch.empty_like(planes)
+        B = planes.numel() // (self.channels * self.N)
+        check(_lib.lib().ddnm_fwht2d_f32(_p(planes), _p(out), B * self.channels, self.img_dim, ops._stream()),
+              "ddnm_fwht2d_f32")
+        return out
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:253-279
+        lam = spectral_coefficients(1.0, a, sigma_y, sigma_t, eta)[0]
+        coef = self._fwht(_flat(vec))
+        coef = _mask_mix(coef, None, self.mask, self.channels, self.N, lam, 1.0)
+        return self._fwht(coef)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :281-320 (no forward transform there)
+        _, d1m, d2m = spectral_coefficients(1.0, a, sigma_y, sigma_t, eta)
+        _, d1n, d2n = spectral_coefficients(0.0, a, sigma_y, sigma_t, eta)
+        mixed = _mask_mix(_flat(vec), _flat(epsilon), self.mask, self.channels, self.N, d1m, d1n, d2m, d2n)
+        return self._fwht(mixed)
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         # A^+(A x0 - y) = H(W .* H x0) - A^+ y ; A^+ y is constant over the run

@@ -22,7 +22,7 @@ import torch.utils.data as data
 
 from .. import dist as ddist
 from .. import ops
-from ..functions.svd_ddnm import _AlphaTable, ddnm_diffusion, get_schedule_jump
+from ..functions.svd_ddnm import _AlphaTable, ddnm_diffusion, ddnm_plus_diffusion, get_schedule_jump
 from ..functions.svd_operators import (Colorization, Denoising, Inpainting, SuperResolution, build_operator)
 from .models import Model
 
@@ -257,8 +257,6 @@ class Diffusion(object):
         A_funcs = build_operator(args.deg, args.deg_scale, config, self.device)
         args.sigma_y = 2 * args.sigma_y          # scaling to [-1, 1] (:524)
         sigma_y = args.sigma_y
-        if sigma_y != 0.0:
-            raise NotImplementedError("sigma_y > 0 (DDNM+, ddnm_plus_diffusion) is the next hot-path row")
         rank, _, world = ddist.env_world()
         print(f"Start from {args.subset_start}")
         idx_so_far = args.subset_start
@@ -286,8 +284,12 @@ class Diffusion(object):
             x = torch.randn(b, config.data.channels, config.data.image_size, config.data.image_size,
                             device=self.device)
             with torch.no_grad():
-                xs, _ = ddnm_diffusion(x, model, self.betas, args.eta, A_funcs, y, cls_fn=cls_fn, classes=classes,
-                                       config=config)
+                if sigma_y == 0.0:       # noise-free case, DDNM (diffusion.py:587-588)
+                    xs, _ = ddnm_diffusion(x, model, self.betas, args.eta, A_funcs, y, cls_fn=cls_fn, classes=classes,
+                                           config=config)
+                else:                    # noisy case, DDNM+ (:589-590)
+                    xs, _ = ddnm_plus_diffusion(x, model, self.betas, args.eta, A_funcs, y, sigma_y, cls_fn=cls_fn,
+                                                classes=classes, config=config)
             img, psnr = ops.finalize_psnr(xs[0], x_orig)
             for j in range(b):
                 save_image(img[j], os.path.join(args.image_folder, f"{idx_so_far + j}_{0}.png"))

@@ -209,6 +209,21 @@ int ddnm_step_denoise_f32(const float* xt, const float* et, int64_t et_bstride, 
 /* time-travel re-noise: xt' = a*x0 + b*noise  (svd_ddnm.py:74) */
 int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_next, int64_t n, float a, float b, void* stream);
 
+/* ---- DDNM+ (sigma_y > 0, functions/svd_ddnm.py:80-164) building blocks --------------------------------- */
+/* out = a*x + b*y (y may be NULL) */
+int ddnm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream);
+/* out = (m ? cx_m : cx_n)*x + (m ? cy_m : cy_n)*y with m = mask[plane % planes_mask][p] != 0 (mask NULL: all measured):
+ * Lambda / Lambda_noise of Inpainting (svd_operators.py:361-439), spectral weights of WalshHadamardCS (:253-320). */
+int ddnm_mask_mix_f32(const float* x, const float* y, const float* mask, int32_t planes_mask, int64_t plane_elems,
+                      float* out, int64_t total, float cx_m, float cx_n, float cy_m, float cy_n, void* stream);
+/* Per-site spectral ops with the n x n orthogonal V (device, row-major) of a 1 x n measurement row:
+ * mode 0 = r x r patches of [B*C][H][W] planes (SuperResolution, :535-623), mode 1 = RGB needles (Colorization, :669-736);
+ * op 0: out = x + (c0-1) V[:,0] (V[:,0].x)  (Lambda, c0 = lambda of the measured direction);
+ * op 1: out = V (d1 .* x_raw + d2 .* y_raw), d1 = (c0, c1, c1, ...), d2 = (c2, c3, c3, ...)  (Lambda_noise). */
+int ddnm_site_spectral_f32(const float* x, const float* y, const float* V, int32_t n, int32_t mode, int32_t r,
+                           int32_t B, int32_t C, int32_t H, int32_t W, float* out, int32_t op, float c0, float c1,
+                           float c2, float c3, void* stream);
+
 /* Stand-alone operator kernels (A and A^+ of functions/svd_operators.py, direct form). */
 int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
 int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);

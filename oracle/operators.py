@@ -203,3 +203,161 @@ class SRConv:
         b = y.shape[0]
         Y = y.reshape(b * self.channels, self.small, self.small)
         return (self.Pe @ Y @ self.Pe.T).reshape(b, -1)
+
+
+# =================================================================================================
+# DDNM+ (sigma_y > 0): Lambda / Lambda_noise restated (functions/svd_operators.py, per class)
+#
+#   lambda_i = s_i*sigma_t*sqrt(1-eta^2)/(a*sigma_y)  where sigma_t < a*sigma_y/s_i, else 1   (s_i = 0 -> 1)
+#   (d1, d2)_i = (sigma_t*eta, 0)                              where sigma_t < a*sigma_y/s_i
+#              = (sqrt(sigma_t^2 - a^2 sigma_y^2 / s_i^2), 0)  where sigma_t > a*sigma_y/s_i
+#              = (sigma_t*eta, sigma_t*sqrt(1-eta^2))          where s_i = 0 (and in the measure-zero tie)
+#   Lambda(v)          = V diag(lambda) V^T v
+#   Lambda_noise(v, e) = V (d1 * v~ + d2 * e~)   with v~, e~ the RAW patch / needle / permuted entries of v, e
+#                        (the reference does not apply V^T to them: svd_operators.py:573-623,697-736,281-320)
+# =================================================================================================
+def _coef(s, a, sigma_y, sigma_t, eta):
+    """Per-singular-value (lambda, d1, d2) as python floats; `s` a float singular value (0 = null space)."""
+    a, sigma_y, sigma_t = float(a), float(sigma_y), float(sigma_t)
+    c1, c2 = sigma_t * eta, sigma_t * (1 - eta ** 2) ** 0.5
+    if s == 0 or a == 0 or sigma_y == 0:
+        return 1.0, c1, c2
+    thr = a * sigma_y / s
+    if sigma_t < thr:
+        return s * sigma_t * (1 - eta ** 2) ** 0.5 / a / sigma_y, c1, 0.0
+    if sigma_t > thr:
+        return 1.0, (sigma_t ** 2 - a ** 2 * sigma_y ** 2 / s ** 2) ** 0.5, 0.0
+    return 1.0, c1, c2
+
+
+def _lambda_denoising(self, vec, a, sigma_y, sigma_t, eta):          # svd_operators.py:464-469
+    if sigma_t < a * sigma_y:
+        return vec * float(sigma_t * (1 - eta ** 2) ** 0.5 / a / sigma_y)
+    return vec
+
+
+def _lambda_noise_denoising(self, vec, a, sigma_y, sigma_t, eta, epsilon):   # :471-476 (epsilon unused)
+    if sigma_t >= a * sigma_y:
+        return vec * float((sigma_t ** 2 - a ** 2 * sigma_y ** 2) ** 0.5)
+    return vec * sigma_t * eta
+
+
+Denoising.Lambda, Denoising.Lambda_noise = _lambda_denoising, _lambda_noise_denoising
+
+
+def _small_svd(row):
+    """V of the 1 x n measurement row (torch.svd on CPU, some=False) -- svd_operators.py:487,633."""
+    U, S, V = torch.svd(torch.tensor([row], dtype=torch.float32), some=False)
+    return float(S[0]), V
+
+
+def _sr_patches(self, v):
+    b = v.shape[0]
+    r = self.ratio
+    p = v.reshape(b, self.channels, self.img_dim, self.img_dim).unfold(2, r, r).unfold(3, r, r)
+    return p.contiguous().reshape(b, self.channels, -1, r * r)
+
+
+def _sr_unpatch(self, p, b):
+    r, yd = self.ratio, self.img_dim // self.ratio
+    p = p.reshape(b, self.channels, yd, yd, r, r).permute(0, 1, 2, 4, 3, 5).contiguous()
+    return p.reshape(b, self.channels * self.img_dim ** 2)
+
+
+def _sr_lambda(self, vec, a, sigma_y, sigma_t, eta):                  # :535-571
+    s, V = _small_svd([1 / self.ratio ** 2] * self.ratio ** 2)
+    lam = torch.ones(self.ratio ** 2)
+    lam[0] = _coef(s, a, sigma_y, sigma_t, eta)[0]
+    p = _sr_patches(self, vec)
+    p = (p @ V) * lam                         # V^T applied to every patch (row-vector form), then lambda
+    return _sr_unpatch(self, p @ V.T, vec.shape[0])
+
+
+def _sr_lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):   # :573-623
+    s, V = _small_svd([1 / self.ratio ** 2] * self.ratio ** 2)
+    n = self.ratio ** 2
+    _, d1m, d2m = _coef(s, a, sigma_y, sigma_t, eta)
+    _, d1n, d2n = _coef(0.0, a, sigma_y, sigma_t, eta)
+    d1, d2 = torch.full((n,), d1n), torch.full((n,), d2n)
+    d1[0], d2[0] = d1m, d2m
+    pv, pe = _sr_patches(self, vec) * d1, _sr_patches(self, epsilon) * d2
+    return _sr_unpatch(self, pv @ V.T, vec.shape[0]) + _sr_unpatch(self, pe @ V.T, vec.shape[0])
+
+
+SuperResolution.Lambda, SuperResolution.Lambda_noise = _sr_lambda, _sr_lambda_noise
+
+
+def _color_lambda(self, vec, a, sigma_y, sigma_t, eta):               # :669-695
+    s, V = _small_svd(list(self.W))
+    lam = torch.ones(3)
+    lam[0] = _coef(s, a, sigma_y, sigma_t, eta)[0]
+    needles = vec.reshape(vec.shape[0], 3, -1).permute(0, 2, 1)      # B, HW, 3
+    out = ((needles @ V) * lam) @ V.T
+    return out.permute(0, 2, 1).reshape(vec.shape[0], -1)
+
+
+def _color_lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):   # :697-736
+    s, V = _small_svd(list(self.W))
+    _, d1m, d2m = _coef(s, a, sigma_y, sigma_t, eta)
+    _, d1n, d2n = _coef(0.0, a, sigma_y, sigma_t, eta)
+    d1, d2 = torch.tensor([d1m, d1n, d1n]), torch.tensor([d2m, d2n, d2n])
+    nv = vec.reshape(vec.shape[0], 3, -1).permute(0, 2, 1) * d1
+    ne = epsilon.reshape(vec.shape[0], 3, -1).permute(0, 2, 1) * d2
+    out = nv @ V.T + ne @ V.T
+    return out.permute(0, 2, 1).reshape(vec.shape[0], -1)
+
+
+Colorization.Lambda, Colorization.Lambda_noise = _color_lambda, _color_lambda_noise
+
+
+def _inp_mask(self, b, like):
+    m = torch.zeros(self.channels * self.img_dim ** 2, dtype=torch.bool)
+    m[self.kept] = True
+    return m.reshape(-1, self.channels).permute(1, 0).reshape(1, -1).expand(b, -1)      # CHW-flat mask of kept entries
+
+
+def _inp_lambda(self, vec, a, sigma_y, sigma_t, eta):                 # :361-387
+    lam = _coef(1.0, a, sigma_y, sigma_t, eta)[0]
+    v = vec.reshape(vec.shape[0], -1)
+    return torch.where(_inp_mask(self, v.shape[0], v), v * lam, v)
+
+
+def _inp_lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):  # :389-439
+    _, d1m, d2m = _coef(1.0, a, sigma_y, sigma_t, eta)
+    _, d1n, d2n = _coef(0.0, a, sigma_y, sigma_t, eta)
+    v, e = vec.reshape(vec.shape[0], -1), epsilon.reshape(vec.shape[0], -1)
+    return torch.where(_inp_mask(self, v.shape[0], v), v * d1m + e * d2m, v * d1n + e * d2n)
+
+
+Inpainting.Lambda, Inpainting.Lambda_noise = _inp_lambda, _inp_lambda_noise
+
+
+def _wh_measured(self):
+    """[C][N] bool: spectral entry (c, q) is measured iff (invperm[q]*C + c) < n_keep."""
+    k = torch.arange(self.img_dim ** 2)
+    m = torch.zeros(self.channels, self.img_dim ** 2, dtype=torch.bool)
+    for c in range(self.channels):
+        m[c, self.perm] = (k * self.channels + c) < self.n_keep
+    return m
+
+
+def _wh_lambda(self, vec, a, sigma_y, sigma_t, eta):                  # :253-279
+    lam = _coef(1.0, a, sigma_y, sigma_t, eta)[0]
+    m = _wh_measured(self)
+    coef = self.fwht(vec)
+    coef = torch.where(m[None], coef * lam, coef)
+    return self.fwht(coef).reshape(vec.shape[0], -1)
+
+
+def _wh_lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):   # :281-320 (no forward transform of vec / epsilon)
+    _, d1m, d2m = _coef(1.0, a, sigma_y, sigma_t, eta)
+    _, d1n, d2n = _coef(0.0, a, sigma_y, sigma_t, eta)
+    m = _wh_measured(self)[None]
+    v = vec.reshape(vec.shape[0], self.channels, -1)
+    e = epsilon.reshape(vec.shape[0], self.channels, -1)
+    tv = torch.where(m, v * d1m, v * d1n)
+    te = torch.where(m, e * d2m, e * d2n)
+    return (self.fwht(tv) + self.fwht(te)).reshape(vec.shape[0], -1)
+
+
+WalshHadamardCS.Lambda, WalshHadamardCS.Lambda_noise = _wh_lambda, _wh_lambda_noise

@@ -98,3 +98,37 @@ def psnr(x, x_orig):
     b = torch.clamp((x_orig + 1) / 2, 0, 1)
     mse = ((a - b) ** 2).reshape(a.shape[0], -1).mean(1)
     return 10 * torch.log10(1 / mse)
+
+
+def ddnm_plus_diffusion(x, model, betas, eta, A_funcs, y, sigma_y, noise, T_sampling=100, travel_length=1,
+                        travel_repeat=1, num_timesteps=1000):
+    """functions/svd_ddnm.py:80-164 (Eq. 17 / Eq. 51): spectral lambda_t on the correction, Lambda_noise on
+    the stochastic term.  `sigma_y` is the already doubled value (diffusion.py:524)."""
+    skip = num_timesteps // T_sampling
+    n = x.shape[0]
+    times = schedule.jump_times(T_sampling, travel_length, travel_repeat)
+    x0_last, xt = None, x
+    tape = iter(noise)
+    with torch.no_grad():
+        for i, j in zip(times[:-1], times[1:]):
+            i, j = i * skip, j * skip
+            if j < 0:
+                j = -1
+            at_next = schedule.alpha_bar(betas, j)
+            if j < i:
+                t = torch.ones(n) * i
+                at = schedule.alpha_bar(betas, i)
+                et = model(xt, t)
+                if et.shape[1] == 6:
+                    et = et[:, :3]
+                x0_t = (xt - et * (1 - at).sqrt()) / at.sqrt()
+                sigma_t = (1 - at_next).sqrt()
+                a = at_next.sqrt()
+                corr = A_funcs.A_pinv(A_funcs.A(x0_t.reshape(n, -1)) - y.reshape(n, -1)).reshape(n, -1)
+                x0_hat = x0_t - A_funcs.Lambda(corr, a, sigma_y, sigma_t, eta).reshape(*x0_t.shape)
+                nz = A_funcs.Lambda_noise(next(tape).reshape(n, -1), a, sigma_y, sigma_t, eta, et.reshape(n, -1))
+                xt = a * x0_hat + nz.reshape(*x0_t.shape)
+                x0_last = x0_t
+            else:
+                xt = at_next.sqrt() * x0_last + next(tape) * (1 - at_next).sqrt()
+    return xt, x0_last

@@ -57,6 +57,32 @@ def sub(t, step=8):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
+def make_plus():
+    """ddnm_plus_diffusion (functions/svd_ddnm.py:80-164) of the reference: small celeba net, sigma_y = 0.2
+    (doubled value, as the runner passes it), 20 steps with time travel, every operator that has Lambda."""
+    ns = ref_import.load()
+    R = ns.svd_operators
+    cfg, sd = cases.celeba_net("small")
+    ref = ns.models.Model(cfg)
+    ref.load_state_dict(sd)
+    ref.eval()
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 20, 2, 2
+    n_it = len(schedule.jump_times(20, 2, 2)) - 1
+    d = cfg.data.image_size
+    out = {}
+    for name in ("sr_averagepooling", "colorization", "inpainting", "cs_walshhadamard", "denoising"):
+        x_orig, x_T, tape = cases.sampler_case(cfg, 2, n_it)
+        op = ref_operator(R, name, d)
+        y = op.A(x_orig)
+        gy = torch.Generator().manual_seed(cases.SEED + 9)
+        y = y + 0.2 * torch.randn(y.shape, generator=gy)           # noisy measurement (diffusion.py:549-550)
+        with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+            xs, x0s = ns.svd_ddnm.ddnm_plus_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, 0.2, cls_fn=None,
+                                                      classes=None, config=cfg)
+        out[f"{name}_x"], out[f"{name}_x0"], out[f"{name}_y"] = xs[0].numpy(), x0s[0].numpy(), y.numpy()
+    np.savez_compressed(os.path.join(HERE, "ddnm_plus_small.npz"), **out)
+
+
 def make_adm():
     """ADM UNetModel (guided_diffusion/unet.py via script_util.create_model), fp32, seeded weights with the
     zero_module'd tensors re-randomised: key list, forwards at three sizes, one sampler run."""
@@ -97,9 +123,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
+    ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
     args = ap.parse_args()
     if args.adm_only:
         return make_adm()
+    if args.plus_only:
+        return make_plus()
     ns = ref_import.load()
     R = ns.svd_operators
     torch.set_num_threads(os.cpu_count())
