@@ -517,3 +517,22 @@ extern "C" int ddnm_site_spectral_f32(const float* x, const float* y, const floa
                 (int64_t)H * W, out, total, op, c0, c1, c2, c3);
     return 0;
 }
+
+// out = x .* table[(plane % planes_table)][p]  -- per-(channel, spectral index) gains of the separable blur
+// operators (functions/svd_operators.py:934-1165: singular values applied between the V^T . V and U . U^T products)
+__global__ __launch_bounds__(256) void mul_planes_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                                         int planes_table, int64_t plane_elems,
+                                                         float* __restrict__ out, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / plane_elems, p = i - plane * plane_elems;
+        out[i] = x[i] * table[(plane % planes_table) * plane_elems + p];
+    }
+}
+
+extern "C" int ddnm_mul_planes_f32(const float* x, const float* table, int32_t planes_table, int64_t plane_elems,
+                                   float* out, int64_t total, void* stream) {
+    if (!x || !table || !out || planes_table <= 0 || plane_elems <= 0 || total <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(mul_planes_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, table, planes_table,
+                plane_elems, out, total);
+    return 0;
+}

@@ -466,6 +466,84 @@ class SRConv(A_functions):
         ops.step_combine(x0_out, proj, None, noise, et, s, out=xt_next)
 
 
+class Deblurring2D(A_functions):
+    """Separable blur A = (U1 (x) U2) diag(g) (V1 (x) V2)^T (svd_operators.py:1094-1165), applied as four
+    N x N MFMA GEMMs per plane + one gain kernel.  The gain table reproduces the reference's tiling quirk
+    (`singulars()` = sorted values repeated 3x against a (position, channel)-interleaved spectral vector):
+    entry (k, c) is scaled by s_sorted[(3k + c) mod N^2]; `A_pinv` inverts the same table (:1014-1023)."""
+
+    ZERO = 3e-2
+
+    def __init__(self, kernel1, kernel2, channels, img_dim, device):
+        self.channels, self.img_dim, self.device = channels, img_dim, device
+        n = img_dim
+
+        def blur_matrix(kernel):
+            k = kernel.detach().float().cpu()
+            A = torch.zeros(n, n)
+            half = k.shape[0] // 2
+            for i in range(n):
+                for j in range(i - half, i + half):
+                    if 0 <= j < n:
+                        A[i, j] = k[j - i + half]
+            return A
+        U1, S1, V1 = torch.svd(blur_matrix(kernel1), some=False)          # host-side setup like the reference ctor
+        U2, S2, V2 = torch.svd(blur_matrix(kernel2), some=False)
+        S1, S2 = S1.clone(), S2.clone()
+        S1[S1 < self.ZERO] = 0
+        S2[S2 < self.ZERO] = 0
+        big = torch.matmul(S1.reshape(n, 1), S2.reshape(1, n)).reshape(n * n)
+        s_sorted, perm = big.sort(descending=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n * n)
+        idx = (3 * inv[None, :] + torch.arange(channels)[:, None]) % (n * n)
+        G = s_sorted[idx]
+        self._singulars = s_sorted.to(device)
+        self.G = G.contiguous().to(device)
+        self.Ginv = torch.where(G > 0, 1.0 / G, torch.zeros_like(G)).contiguous().to(device)
+        dv = lambda m: m.contiguous().to(device)                            # noqa: E731
+        self.U1, self.U1t, self.V1, self.V1t = dv(U1), dv(U1.T), dv(V1), dv(V1.T)
+        self.U2, self.U2t, self.V2, self.V2t = dv(U2), dv(U2.T), dv(V2), dv(V2.T)
+
+    def _sandwich(self, L, x, Rt_rows, gain, L2, R2_rows):
+        """out = L2 . (gain .* (L . X . R)) . R2  for every plane; Rt_rows / R2_rows hold R^T / R2^T row-major
+        (= the `[N][K]` operand layout of the GEMM)."""
+        bc, n = x.shape[0] * self.channels, self.img_dim
+        t1 = torch.empty(bc, n, n, dtype=torch.float32, device=x.device)
+        ops.bgemm(L, x, t1, n, n, n, lda=n, ldb=n, ldc=n, transb=False, batch=bc, sB=(n * n, 0), sC=(n * n, 0))
+        t2 = torch.empty_like(t1)
+        ops.bgemm(t1, Rt_rows, t2, n, n, n, lda=n, ldb=n, ldc=n, transb=True, batch=bc, sA=(n * n, 0), sC=(n * n, 0))
+        check(_lib.lib().ddnm_mul_planes_f32(_p(t2), _p(gain), self.channels, n * n, _p(t2), t2.numel(), ops._stream()),
+              "ddnm_mul_planes_f32")
+        ops.bgemm(L2, t2, t1, n, n, n, lda=n, ldb=n, ldc=n, transb=False, batch=bc, sB=(n * n, 0), sC=(n * n, 0))
+        out = torch.empty(x.shape[0], self.channels * n * n, dtype=torch.float32, device=x.device)
+        ops.bgemm(t1, R2_rows, out, n, n, n, lda=n, ldb=n, ldc=n, transb=True, batch=bc, sA=(n * n, 0), sC=(n * n, 0))
+        return out
+
+    def A(self, vec):
+        x = _img(vec, self.channels, self.img_dim)
+        # V1^T X V2 -> gains -> U1 (.) U2^T ;  X . V2 = X . (V2^T)^T, (.) . U2^T uses U2 rows
+        return self._sandwich(self.V1t, x, self.V2t, self.G, self.U1, self.U2)
+
+    def A_pinv(self, vec):
+        y = _img(vec, self.channels, self.img_dim)
+        return self._sandwich(self.U1t, y, self.U2t, self.Ginv, self.V1, self.V2)
+
+    def singulars(self):
+        return self._singulars.repeat(1, 3).reshape(-1)
+
+
+class Deblurring(Deblurring2D):
+    def __init__(self, kernel, channels, img_dim, device, ZERO=3e-2):
+        self.ZERO = ZERO
+        super().__init__(kernel, kernel, channels, img_dim, device)
+
+
+def gaussian_taps(sigma, radius):
+    """diffusion.py:507-520: fp32 exp(-0.5 (x/sigma)^2) for x = -radius..radius."""
+    return torch.tensor([float(torch.exp(torch.Tensor([-0.5 * (x / sigma) ** 2]))) for x in range(-radius, radius + 1)])
+
+
 def build_operator(deg, deg_scale, config, device, mask_path="exp/inp_masks/mask.npy", perm=None):
     """Operator factory of guided_diffusion/diffusion.py:451-523 for the --deg values on the hot path."""
     c, d = config.data.channels, config.data.image_size
@@ -487,6 +565,17 @@ def build_operator(deg, deg_scale, config, device, mask_path="exp/inp_masks/mask
     if deg == "sr_bicubic":
         factor = int(deg_scale)
         return SRConv(bicubic_kernel(factor), c, d, device, stride=factor)
+    if deg == "deblur_uni":
+        return Deblurring(torch.Tensor([1 / 9] * 9), c, d, device)
+    if deg == "deblur_gauss":
+        k = gaussian_taps(10, 2)
+        return Deblurring(k / k.sum(), c, d, device)
+    if deg == "deblur_aniso":
+        k2, k1 = gaussian_taps(20, 4), gaussian_taps(1, 4)
+        return Deblurring2D(k1 / k1.sum(), k2 / k2.sum(), c, d, device)
+    if deg == "cs_blockbased":
+        raise NotImplementedError("block-based CS draws its sensing matrix from the device RNG (svd_operators.py:107); "
+                                  "listed under 'next' (SURVEY.md section 8f rank 2)")
     raise ValueError("degradation type not supported")
 
 

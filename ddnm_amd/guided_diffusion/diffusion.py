@@ -272,7 +272,9 @@ class Diffusion(object):
             if args.add_noise:
                 y = y + torch.randn_like(y) * sigma_y
             Apy = A_funcs.A_pinv(y).view(b, config.data.channels, config.data.image_size, config.data.image_size)
-            if args.deg == "colorization":
+            if args.deg[:6] == "deblur":
+                Apy = y.view(b, config.data.channels, config.data.image_size, config.data.image_size)
+            elif args.deg == "colorization":
                 Apy = y.view(b, 1, config.data.image_size, config.data.image_size).repeat(1, 3, 1, 1)
             elif args.deg == "inpainting":
                 Apy = Apy + A_funcs.A_pinv(A_funcs.A(torch.ones_like(Apy))).reshape(*Apy.shape) - 1

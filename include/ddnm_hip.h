@@ -224,6 +224,10 @@ int ddnm_site_spectral_f32(const float* x, const float* y, const float* V, int32
                            int32_t B, int32_t C, int32_t H, int32_t W, float* out, int32_t op, float c0, float c1,
                            float c2, float c3, void* stream);
 
+/* out = x .* table[plane % planes_table][p]: spectral gains of Deblurring / Deblurring2D (svd_operators.py:934-1165) */
+int ddnm_mul_planes_f32(const float* x, const float* table, int32_t planes_table, int64_t plane_elems, float* out,
+                        int64_t total, void* stream);
+
 /* Stand-alone operator kernels (A and A^+ of functions/svd_operators.py, direct form). */
 int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
 int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);

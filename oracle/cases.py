@@ -62,6 +62,14 @@ def make_operator(name, img_dim, mask=None):
         return O.WalshHadamardCS(3, img_dim, 4, wh_perm(img_dim))
     if name == "denoising":
         return O.Denoising(3, img_dim)
+    if name == "deblur_uni":
+        return O.Deblurring(torch.Tensor([1 / 9] * 9), 3, img_dim)
+    if name == "deblur_gauss":
+        k = O.gaussian_taps(10, 2)
+        return O.Deblurring(k / k.sum(), 3, img_dim)
+    if name == "deblur_aniso":
+        k2, k1 = O.gaussian_taps(20, 4), O.gaussian_taps(1, 4)
+        return O.Deblurring2D(k1 / k1.sum(), k2 / k2.sum(), 3, img_dim)
     raise ValueError(name)
 
 

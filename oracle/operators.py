@@ -361,3 +361,70 @@ def _wh_lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):   # :281-320
 
 
 WalshHadamardCS.Lambda, WalshHadamardCS.Lambda_noise = _wh_lambda, _wh_lambda_noise
+
+
+# =================================================================================================
+# Separable blur operators (functions/svd_operators.py:934-1091 Deblurring, :1094-1165 Deblurring2D)
+# =================================================================================================
+def blur_matrix(kernel, img_dim):
+    """1-D convolution matrix with zero boundary, svd_operators.py:947-951."""
+    A = torch.zeros(img_dim, img_dim)
+    half = kernel.shape[0] // 2
+    for i in range(img_dim):
+        for j in range(i - half, i + half):
+            if j < 0 or j >= img_dim:
+                continue
+            A[i, j] = kernel[j - i + half]
+    return A
+
+
+class Deblurring2D:
+    """A = U diag(g) V^T with U = U1 (x) U2, V = V1 (x) V2 (row/column blur), singular values s1_i*s2_j
+    (1-D values below 3e-2 zeroed), sorted descending.  REFERENCE QUIRK reproduced: `singulars()` tiles the
+    sorted values 3x (`repeat(1, 3)`, :1012,1154) while the spectral vector is (position, channel)-interleaved,
+    so entry (k, c) is scaled by s_sorted[(3k + c) mod N^2]; `A_pinv` uses the same tiling (:1014-1023)."""
+
+    ZERO = 3e-2
+
+    def __init__(self, kernel1, kernel2, channels, img_dim):
+        self.channels, self.img_dim = channels, img_dim
+        n = img_dim
+        U1, S1, V1 = torch.svd(blur_matrix(kernel1.float().cpu(), n), some=False)
+        U2, S2, V2 = torch.svd(blur_matrix(kernel2.float().cpu(), n), some=False)
+        S1, S2 = S1.clone(), S2.clone()
+        S1[S1 < self.ZERO] = 0
+        S2[S2 < self.ZERO] = 0
+        big = torch.matmul(S1.reshape(n, 1), S2.reshape(1, n)).reshape(n * n)
+        s_sorted, perm = big.sort(descending=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n * n)
+        idx = (3 * inv[None, :] + torch.arange(channels)[:, None]) % (n * n)          # [C][N^2]
+        self.G = s_sorted[idx]                                                            # gain of spectral entry (c, q)
+        self.Ginv = torch.where(self.G > 0, 1.0 / self.G, torch.zeros_like(self.G))
+        self.U1, self.V1, self.U2, self.V2 = U1, V1, U2, V2
+        self._singulars = s_sorted
+
+    def _planes(self, v):
+        return v.reshape(v.shape[0], self.channels, self.img_dim, self.img_dim)
+
+    def A(self, x):
+        b = x.shape[0]
+        T = self.V1.T @ self._planes(x) @ self.V2
+        T = T * self.G.reshape(1, self.channels, self.img_dim, self.img_dim)
+        return (self.U1 @ T @ self.U2.T).reshape(b, -1)
+
+    def A_pinv(self, y):
+        b = y.shape[0]
+        T = self.U1.T @ self._planes(y) @ self.U2
+        T = T * self.Ginv.reshape(1, self.channels, self.img_dim, self.img_dim)
+        return (self.V1 @ T @ self.V2.T).reshape(b, -1)
+
+
+class Deblurring(Deblurring2D):
+    def __init__(self, kernel, channels, img_dim):
+        super().__init__(kernel, kernel, channels, img_dim)
+
+
+def gaussian_taps(sigma, radius):
+    """diffusion.py:507-520: exp(-0.5 (x/sigma)^2) evaluated in fp32, x = -radius..radius."""
+    return torch.tensor([float(torch.exp(torch.Tensor([-0.5 * (x / sigma) ** 2]))) for x in range(-radius, radius + 1)])

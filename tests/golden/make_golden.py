@@ -50,11 +50,45 @@ def ref_operator(R, name, d, mask=None):
         return R.WalshHadamardCS(3, d, 4, cases.wh_perm(d), "cpu")
     if name == "denoising":
         return R.Denoising(3, d, "cpu")
+    from oracle import operators as O
+    if name == "deblur_uni":                                                 # diffusion.py:500-503
+        return R.Deblurring(torch.Tensor([1 / 9] * 9), 3, d, "cpu")
+    if name == "deblur_gauss":                                               # :504-509
+        k = O.gaussian_taps(10, 2)
+        return R.Deblurring(k / k.sum(), 3, d, "cpu")
+    if name == "deblur_aniso":                                               # :510-521
+        k2, k1 = O.gaussian_taps(20, 4), O.gaussian_taps(1, 4)
+        return R.Deblurring2D(k1 / k1.sum(), k2 / k2.sum(), 3, d, "cpu")
     raise ValueError(name)
 
 
 def sub(t, step=8):
     return t[..., ::step, ::step].contiguous().numpy()
+
+
+def make_deblur():
+    """Deblurring / Deblurring2D of the reference: A, A_pinv at 64^2 and one 12-step sampler run (small net)."""
+    ns = ref_import.load()
+    R = ns.svd_operators
+    out = {}
+    x = cases.operator_input(64, 2)
+    for name in ("deblur_uni", "deblur_gauss", "deblur_aniso"):
+        op = ref_operator(R, name, 64)
+        y = op.A(x)
+        out[f"{name}_y"], out[f"{name}_pinv"] = y.numpy(), op.A_pinv(y.clone()).numpy()
+    cfg, sd = cases.celeba_net("small")
+    ref = ns.models.Model(cfg)
+    ref.load_state_dict(sd)
+    ref.eval()
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 12, 1, 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 2, 12)
+    op = ref_operator(R, "deblur_gauss", cfg.data.image_size)
+    y = op.A(x_orig)
+    with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+        xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, cls_fn=None, classes=None,
+                                             config=cfg)
+    out["sampler_gauss_x"], out["sampler_gauss_x0"] = xs[0].numpy(), x0s[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "deblur.npz"), **out)
 
 
 def make_plus():
@@ -124,7 +158,10 @@ def main():
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
+    ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     args = ap.parse_args()
+    if args.deblur_only:
+        return make_deblur()
     if args.adm_only:
         return make_adm()
     if args.plus_only:

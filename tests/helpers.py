@@ -30,6 +30,9 @@ def engine_operator(name, d, mask=None, device="cuda"):
         return E.WalshHadamardCS(3, d, 4, cases.wh_perm(d), device)
     if name == "denoising":
         return E.Denoising(3, d, device)
+    if name in ("deblur_uni", "deblur_gauss", "deblur_aniso"):
+        cfg = cases.weights.celeba_config(resolution=d)
+        return E.build_operator(name, 0, cfg, device)
     raise ValueError(name)
 
 
