@@ -39,6 +39,7 @@ class GemmDesc(Structure):
         ("sAo", c_int64), ("sAi", c_int64), ("sBo", c_int64), ("sBi", c_int64),
         ("sCo", c_int64), ("sCi", c_int64), ("sDo", c_int64), ("sDi", c_int64),
         ("alpha", c_float), ("beta", c_float),
+        ("transa", c_int32), ("reserved", c_int32),
     ]
 
 
@@ -57,7 +58,7 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                              c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
-                                             c_void_p]),
+                                             c_void_p, c_void_p]),
     "ddnm_conv3x3_f16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv3x3_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
@@ -66,8 +67,20 @@ PROTOTYPES = {
                                     c_int32, c_void_p]),
     "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),
     "ddnm_gn_finalize_f32": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
-                                       c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                                       c_float, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "ddnm_bgemm_f32": (c_int32, [POINTER(GemmDesc), c_void_p]),
+    "ddnm_gn_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                  c_void_p]),
+    "ddnm_gn_bwd_nchunk": (c_int32, [c_int32, c_int32]),
+    "ddnm_softmax_bwd_rows_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "ddnm_pool_tokens_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                       c_void_p]),
+    "ddnm_pool_attn_fwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_pool_attn_bwd_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                         c_void_p]),
+    "ddnm_pool_tokens_bwd_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_logsoftmax_grad_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ddnm_softmax_rows_f32": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "ddnm_linear_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                   c_void_p]),
@@ -89,6 +102,8 @@ PROTOTYPES = {
     "ddnm_step_denoise_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int32, c_int64, POINTER(StepScalars), c_void_p]),
     "ddnm_axpby_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ddnm_axpby_strided_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int64, c_float, c_float,
+                                         c_void_p]),
     "ddnm_mask_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_float, c_float,
                                     c_float, c_float, c_void_p]),
     "ddnm_site_spectral_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,

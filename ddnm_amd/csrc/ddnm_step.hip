@@ -536,3 +536,22 @@ extern "C" int ddnm_mul_planes_f32(const float* x, const float* table, int32_t p
                 plane_elems, out, total);
     return 0;
 }
+
+// out[b][i] = a * x[b*x_bstride + i] + b * y[b*chw + i]: eps <- eps[:, :3] - sqrt(1-abar) * grad  (svd_ddnm.py:51-52)
+__global__ __launch_bounds__(256) void axpby_strided_kernel(const float* __restrict__ x, int64_t x_bstride,
+                                                            const float* __restrict__ y, float* __restrict__ out,
+                                                            int64_t chw, int64_t total, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t bi = i / chw, r = i - bi * chw;
+        out[i] = x[bi * x_bstride + r] * a + y[i] * b;
+    }
+}
+
+extern "C" int ddnm_axpby_strided_f32(const float* x, int64_t x_bstride, const float* y, float* out, int32_t B,
+                                      int64_t chw, float a, float b, void* stream) {
+    if (!x || !y || !out || B <= 0 || chw <= 0) return DDNM_E_BADARG;
+    const int64_t total = (int64_t)B * chw;
+    DDNM_LAUNCH(axpby_strided_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, x_bstride, y, out, chw,
+                total, a, b);
+    return 0;
+}

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(const ddnm_gemm_desc d, 
     const int bi = blockIdx.x / per_batch, t = blockIdx.x - bi * per_batch;
     const int m_tile = t / n_tiles, n_tile = t - m_tile * n_tiles;
     const int bo = bi / d.inner, bn = bi - bo * d.inner;
-    const float* A = d.A + bo * d.sAo + bn * d.sAi + (size_t)(m_tile * BM) * d.lda;
+    // transa: A stored [K][M] (lda = row pitch of that storage)
+    const float* A = d.A + bo * d.sAo + bn * d.sAi + (d.transa ? (size_t)(m_tile * BM) : (size_t)(m_tile * BM) * d.lda);
     const float* Bm = d.Bm + bo * d.sBo + bn * d.sBi;
     const int c4 = tid & 7, row0 = tid >> 3;
 
@@ -37,9 +38,18 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(const ddnm_gemm_desc d, 
 
     for (int k0 = 0; k0 < d.K; k0 += KC) {
         f32x4 a_st[AR], b_st[BR];
+        if (!d.transa) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i)
-            a_st[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(row0 + 32 * i) * d.lda + k0 + c4 * 4);
+            for (int i = 0; i < AR; ++i)
+                a_st[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(row0 + 32 * i) * d.lda + k0 + c4 * 4);
+        } else {          // 32 k-rows x BM/4 float4 along m
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BM / 4), m4 = idx - kr * (BM / 4);
+                a_st[i] = *reinterpret_cast<const f32x4*>(A + (size_t)(k0 + kr) * d.lda + m4 * 4);
+            }
+        }
         if (d.transb) {   // B stored [N][K]: same pattern as A
 #pragma unroll
             for (int i = 0; i < BR; ++i)
@@ -53,8 +63,20 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(const ddnm_gemm_desc d, 
             }
         }
         __syncthreads();
+        if (!d.transa) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[(row0 + 32 * i) * LDT + c4 * 4]) = a_st[i];
+            for (int i = 0; i < AR; ++i) *reinterpret_cast<f32x4*>(&As[(row0 + 32 * i) * LDT + c4 * 4]) = a_st[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BM / 4), m4 = idx - kr * (BM / 4);
+                As[(m4 * 4 + 0) * LDT + kr] = a_st[i].x;
+                As[(m4 * 4 + 1) * LDT + kr] = a_st[i].y;
+                As[(m4 * 4 + 2) * LDT + kr] = a_st[i].z;
+                As[(m4 * 4 + 3) * LDT + kr] = a_st[i].w;
+            }
+        }
         if (d.transb) {
 #pragma unroll
             for (int i = 0; i < BR; ++i) *reinterpret_cast<f32x4*>(&Bs[(row0 + 32 * i) * LDT + c4 * 4]) = b_st[i];
@@ -111,14 +133,15 @@ __global__ __launch_bounds__(256) void bgemm_naive_kernel(const ddnm_gemm_desc d
         const int64_t bi = i / per, r = i - bi * per;
         const int m = (int)(r / d.N), n = (int)(r - (int64_t)m * d.N);
         const int64_t bo = bi / d.inner, bn = bi - bo * d.inner;
-        const float* A = d.A + bo * d.sAo + bn * d.sAi + (size_t)m * d.lda;
+        const float* A = d.A + bo * d.sAo + bn * d.sAi + (d.transa ? (size_t)m : (size_t)m * d.lda);
+        const size_t ak = d.transa ? (size_t)d.lda : 1;
         const float* Bm = d.Bm + bo * d.sBo + bn * d.sBi;
         float acc = 0.f;
         if (d.transb) {
             const float* Br = Bm + (size_t)n * d.ldb;
-            for (int k = 0; k < d.K; ++k) acc += A[k] * Br[k];
+            for (int k = 0; k < d.K; ++k) acc += A[k * ak] * Br[k];
         } else {
-            for (int k = 0; k < d.K; ++k) acc += A[k] * Bm[(size_t)k * d.ldb + n];
+            for (int k = 0; k < d.K; ++k) acc += A[k * ak] * Bm[(size_t)k * d.ldb + n];
         }
         float v = d.alpha * acc;
         if (d.D) v += d.beta * d.D[bo * d.sDo + bn * d.sDi + (size_t)m * d.ldd + n];

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
                                                           const float* __restrict__ beta, int HW, int C, int groups,
                                                           float eps, float* __restrict__ scale,
                                                           float* __restrict__ shift,
-                                                          const float* __restrict__ film, int film_stride) {
+                                                          const float* __restrict__ film, int film_stride,
+                                                          float* __restrict__ mean_rstd) {
     __shared__ double acc[64][4][2];
     __shared__ float mean_s[64], rstd_s[64];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -101,6 +102,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
         var = var > 0.0 ? var : 0.0;
         mean_s[g] = (float)mean;
         rstd_s[g] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mean_rstd) {                      // kept for the backward pass (classifier input gradient)
+            mean_rstd[((size_t)b * groups + g) * 2 + 0] = mean_s[g];
+            mean_rstd[((size_t)b * groups + g) * 2 + 1] = rstd_s[g];
+        }
     }
     __syncthreads();
     const int cpg = C / groups;
@@ -120,11 +125,12 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 
 extern "C" int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gamma, const float* beta,
                                     int32_t B, int32_t HW, int32_t C, int32_t groups, float eps, float* scale,
-                                    float* shift, const float* film, int32_t film_stride, void* stream) {
+                                    float* shift, const float* film, int32_t film_stride, float* mean_rstd,
+                                    void* stream) {
     if (!partial || !gamma || !beta || !scale || !shift || B <= 0 || nchunk <= 0) return DDNM_E_BADARG;
     if (groups <= 0 || groups > 64 || C % groups) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, nchunk, gamma, beta,
-                       HW, C, groups, eps, scale, shift, film, film_stride);
+                       HW, C, groups, eps, scale, shift, film, film_stride, mean_rstd);
     return 0;
 }
 
@@ -138,7 +144,8 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
                                                                 const float* __restrict__ beta, int HW, int groups,
                                                                 float eps, float* __restrict__ scale,
                                                                 float* __restrict__ shift,
-                                                                const float* __restrict__ film, int film_stride) {
+                                                                const float* __restrict__ film, int film_stride,
+                                                                float* __restrict__ mean_rstd) {
     __shared__ double red[256][2];
     __shared__ float mean_s, rstd_s;
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
@@ -176,6 +183,10 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         var = var > 0.0 ? var : 0.0;
         mean_s = (float)mean;
         rstd_s = (float)(1.0 / sqrt(var + (double)eps));
+        if (mean_rstd) {
+            mean_rstd[((size_t)b * groups + g) * 2 + 0] = mean_s;
+            mean_rstd[((size_t)b * groups + g) * 2 + 1] = rstd_s;
+        }
     }
     __syncthreads();
     for (int c = c_lo + tid; c < c_lo + cpg; c += 256) {
@@ -194,12 +205,12 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
 extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int32_t C0, const float* part1,
                                           int32_t tpi1, int32_t C1, const float* gamma, const float* beta, int32_t B,
                                           int32_t HW, int32_t groups, float eps, float* scale, float* shift,
-                                          const float* film, int32_t film_stride, void* stream) {
+                                          const float* film, int32_t film_stride, float* mean_rstd, void* stream) {
     if (!part0 || !gamma || !beta || !scale || !shift || B <= 0 || tpi0 <= 0 || C0 <= 0) return DDNM_E_BADARG;
     if (C1 > 0 && (!part1 || tpi1 <= 0)) return DDNM_E_BADARG;
     const int C = C0 + C1;
     if (groups <= 0 || C % groups) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_tiles_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, part0, tpi0, C0, part1, tpi1,
-                C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride);
+                C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride, mean_rstd);
     return 0;
 }

@@ -69,6 +69,20 @@ class _AlphaTable:
         return self.ab[t + 1]
 
 
+def _guided_eps(et, grad, coef):
+    """eps[:, :3] - sqrt(1 - abar_t) * cls_fn(x, t, y)   (svd_ddnm.py:51-52; note the guidance is evaluated on the
+    INITIAL noise x, not on x_t -- reference quirk kept)."""
+    import ctypes  # noqa: F401
+    from .. import _lib
+    n = et.shape[0]
+    chw = 3 * et.shape[2] * et.shape[3]
+    out = torch.empty(n, 3, et.shape[2], et.shape[3], dtype=torch.float32, device=et.device)
+    grad = grad.float().contiguous()
+    _lib.check(_lib.lib().ddnm_axpby_strided_f32(et.data_ptr(), et.stride(0), grad.data_ptr(), out.data_ptr(), n, chw,
+                                                 1.0, -coef, ops._stream()), "ddnm_axpby_strided_f32")
+    return out
+
+
 def _noise_source(noise, like):
     if noise is None:
         def draw(k):
@@ -114,9 +128,7 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                     et = model(xt, t)
                 else:
                     cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
-                    et = model(xt, t, cls)
-                    et = et[:, :3]
-                    et = (et - (1 - at).sqrt() * cls_fn(x, t, cls)).contiguous()
+                    et = _guided_eps(model(xt, t, cls), cls_fn(x, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:
                     et = et[:, :3]
                 s = ops.step_scalars(at, at_next, eta)
@@ -172,9 +184,7 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                     et = model(xt, t)
                 else:
                     cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
-                    et = model(xt, t, cls)
-                    et = et[:, :3]
-                    et = (et - (1 - at).sqrt() * cls_fn(x, t, cls)).contiguous()
+                    et = _guided_eps(model(xt, t, cls), cls_fn(x, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:
                     et = et[:, :3].contiguous()
                 a, sigma_t = at_next.sqrt(), (1 - at_next).sqrt()

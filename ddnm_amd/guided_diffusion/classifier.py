@@ -1,0 +1,391 @@
+"""Noisy ImageNet classifier + classifier-guidance gradient on MI355X.
+
+Drop-in for `script_util.create_classifier(...)` -> `guided_diffusion/unet.py::EncoderUNetModel`
+(:684-895, pool="attention") and for the `cond_fn` closure of `guided_diffusion/diffusion.py:183-189`:
+
+    cond_fn(x, t, y) = classifier_scale * d/dx log_softmax(classifier(x, t))[y]
+
+The reference gets the gradient from torch autograd.  Here the backward pass is explicit and made of HIP
+kernels only (no autograd, no torch ops): data-gradient convolutions are the forward implicit-GEMM kernels
+run on flipped / transposed weights, GroupNorm(+FiLM)+SiLU backward is `ddnm_gn_bwd_f32`, attention
+backward is four batched MFMA GEMMs + `softmax_bwd_rows`, AttentionPool2d has its own small kernels
+(csrc/backward.hip).  Weight gradients are never formed.  The state-dict (249 tensors, reference names,
+e.g. the public 256x256_classifier.pt) loads unchanged.
+"""
+import ctypes
+import math
+from collections import OrderedDict
+
+import torch
+
+from .. import _lib, ops
+from .._lib import check
+
+GN_EPS = 1e-5
+CIN_PAD = 32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def classifier_defaults():
+    """script_util.py:27-39."""
+    return dict(image_size=64, classifier_use_fp16=False, classifier_width=128, classifier_depth=2,
+                classifier_attention_resolutions="32,16,8", classifier_use_scale_shift_norm=True,
+                classifier_resblock_updown=True, classifier_pool="attention")
+
+
+def args_to_dict(args, keys):
+    return {k: getattr(args, k) for k in keys}
+
+
+def create_classifier(image_size, classifier_use_fp16, classifier_width, classifier_depth,
+                      classifier_attention_resolutions, classifier_use_scale_shift_norm, classifier_resblock_updown,
+                      classifier_pool):
+    """script_util.py:229-267."""
+    table = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+    if image_size not in table:
+        raise ValueError(f"unsupported image size: {image_size}")
+    attention_ds = tuple(image_size // int(r) for r in classifier_attention_resolutions.split(","))
+    return EncoderUNetModel(image_size=image_size, in_channels=3, model_channels=classifier_width, out_channels=1000,
+                            num_res_blocks=classifier_depth, attention_resolutions=attention_ds,
+                            channel_mult=table[image_size], use_fp16=classifier_use_fp16, num_head_channels=64,
+                            use_scale_shift_norm=classifier_use_scale_shift_norm,
+                            resblock_updown=classifier_resblock_updown, pool=classifier_pool)
+
+
+class EncoderUNetModel:
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 channel_mult=(1, 2, 4, 8), use_fp16=False, num_head_channels=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, pool="adaptive", device=None, **kwargs):
+        if pool != "attention" or not use_scale_shift_norm or not resblock_updown or num_head_channels == -1:
+            raise NotImplementedError("only the DDNM classifier configuration (attention pool, FiLM, resblock "
+                                      "up/down, 64-channel heads) is built")
+        self.image_size, self.in_channels, self.model_channels = image_size, in_channels, model_channels
+        self.out_channels, self.head_ch = out_channels, num_head_channels
+        self.time_embed_dim = 4 * model_channels
+        self.device = torch.device("cuda") if device is None else torch.device(device)
+        mc = model_channels
+        ch = int(channel_mult[0] * mc)
+        self.input_blocks = [[("conv", in_channels, ch)]]
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [("res", ch, int(mult * mc), "")]
+                ch = int(mult * mc)
+                if ds in attention_resolutions:
+                    layers.append(("attn", ch))
+                self.input_blocks.append(layers)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append([("res", ch, ch, "down")])
+                ds *= 2
+        self.middle_block = [("res", ch, ch, ""), ("attn", ch), ("res", ch, ch, "")]
+        self.final_ch, self.pool_sp = ch, image_size // ds
+        off, self._film_off = 0, {}
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                if L[0] == "res":
+                    self._film_off[f"{prefix}.{j}"] = off
+                    off += 2 * L[2]
+        self.film_total = off
+        self.w = None
+        self._ws = None
+
+    def _walk(self):
+        for i, layers in enumerate(self.input_blocks):
+            yield f"input_blocks.{i}", layers
+        yield "middle_block", self.middle_block
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def convert_to_fp16(self):
+        """Accepted (diffusion.py:176-177); the classifier and its gradient are evaluated in fp32 here."""
+        return self
+
+    def parameters(self):
+        return iter(())
+
+    def state_dict_shapes(self):
+        s = OrderedDict()
+        ted, mc = self.time_embed_dim, self.model_channels
+        s["time_embed.0.weight"], s["time_embed.0.bias"] = (ted, mc), (ted,)
+        s["time_embed.2.weight"], s["time_embed.2.bias"] = (ted, ted), (ted,)
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if L[0] == "conv":
+                    s[n + ".weight"], s[n + ".bias"] = (L[2], L[1], 3, 3), (L[2],)
+                elif L[0] == "res":
+                    cin, cout = L[1], L[2]
+                    s[n + ".in_layers.0.weight"], s[n + ".in_layers.0.bias"] = (cin,), (cin,)
+                    s[n + ".in_layers.2.weight"], s[n + ".in_layers.2.bias"] = (cout, cin, 3, 3), (cout,)
+                    s[n + ".emb_layers.1.weight"], s[n + ".emb_layers.1.bias"] = (2 * cout, ted), (2 * cout,)
+                    s[n + ".out_layers.0.weight"], s[n + ".out_layers.0.bias"] = (cout,), (cout,)
+                    s[n + ".out_layers.3.weight"], s[n + ".out_layers.3.bias"] = (cout, cout, 3, 3), (cout,)
+                    if cin != cout:
+                        s[n + ".skip_connection.weight"], s[n + ".skip_connection.bias"] = (cout, cin, 1, 1), (cout,)
+                else:
+                    c = L[1]
+                    s[n + ".norm.weight"], s[n + ".norm.bias"] = (c,), (c,)
+                    s[n + ".qkv.weight"], s[n + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
+                    s[n + ".proj_out.weight"], s[n + ".proj_out.bias"] = (c, c, 1), (c,)
+        c = self.final_ch
+        s["out.0.weight"], s["out.0.bias"] = (c,), (c,)
+        s["out.2.positional_embedding"] = (c, self.pool_sp ** 2 + 1)
+        s["out.2.qkv_proj.weight"], s["out.2.qkv_proj.bias"] = (3 * c, c, 1), (3 * c,)
+        s["out.2.c_proj.weight"], s["out.2.c_proj.bias"] = (self.out_channels, c, 1), (self.out_channels,)
+        return s
+
+    def load_state_dict(self, sd, strict=True):
+        dev = self.device
+        g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
+        w = {}
+
+        def conv(name, raw, cin_pad=None):
+            """forward weights and the data-gradient weights (input/output channels swapped, taps flipped)"""
+            if raw.dim() == 3:
+                raw = raw.unsqueeze(-1)
+            w[name + ".weight"] = ops.pack_conv_weight(raw, cin_pad=cin_pad)
+            w[name + ".dgrad"] = ops.pack_conv_weight(raw.permute(1, 0, 2, 3).flip(2, 3).contiguous())
+            w[name + ".bias"] = g(name + ".bias")
+
+        for k in ("time_embed.0", "time_embed.2"):
+            w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
+        fw, fb = [], []
+        for prefix, layers in self._walk():
+            for j, L in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if L[0] == "conv":
+                    conv(n, g(n + ".weight"), cin_pad=CIN_PAD)
+                elif L[0] == "res":
+                    for norm in ("in_layers.0", "out_layers.0"):
+                        w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
+                    conv(n + ".in_layers.2", g(n + ".in_layers.2.weight"))
+                    conv(n + ".out_layers.3", g(n + ".out_layers.3.weight"))
+                    fw.append(g(n + ".emb_layers.1.weight"))
+                    fb.append(g(n + ".emb_layers.1.bias"))
+                    if L[1] != L[2]:
+                        conv(n + ".skip_connection", g(n + ".skip_connection.weight"))
+                else:
+                    w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
+                    conv(n + ".qkv", g(n + ".qkv.weight"))
+                    conv(n + ".proj_out", g(n + ".proj_out.weight"))
+        w["film_cat.weight"], w["film_cat.bias"] = torch.cat(fw, 0).contiguous(), torch.cat(fb, 0).contiguous()
+        w["out.0.weight"], w["out.0.bias"] = g("out.0.weight"), g("out.0.bias")
+        w["pool.pos"] = g("out.2.positional_embedding")
+        wq = g("out.2.qkv_proj.weight").squeeze(-1).contiguous()              # [3C, C]
+        w["pool.qkv.weight"], w["pool.qkv.bias"] = wq, g("out.2.qkv_proj.bias")
+        wc = g("out.2.c_proj.weight").squeeze(-1).contiguous()                # [1000, C]
+        w["pool.c.weight"], w["pool.c.weight_t"], w["pool.c.bias"] = wc, wc.t().contiguous(), g("out.2.c_proj.bias")
+        half = self.model_channels // 2
+        w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+        self.w = w
+        self._ws = None
+        return self
+
+    # ------------------------------------------------------------------ forward (optionally recording a tape)
+    def _workspace(self, B):
+        if self._ws is None or self._ws_B < B:
+            res, mp, mpb = self.image_size, 0, 0
+            while res >= 4:
+                for c in (self.model_channels, self.final_ch):
+                    mp = max(mp, ops.gn_nchunk(res * res, c))
+                    mpb = max(mpb, _lib.lib().ddnm_gn_bwd_nchunk(res * res, c))
+                res //= 2
+            self._ws = ops.GroupNormWorkspace(self.device, B, self.final_ch, B * mp * 32 * 2)
+            self._bwd_partial = torch.empty(B * mpb * 32 * 2, dtype=torch.float64, device=self.device)
+            self._bwd_coef = torch.empty(B * 32 * 2, dtype=torch.float32, device=self.device)
+            self._ws_B = B
+        return self._ws
+
+    def _gn(self, x, name, film=None, keep=None):
+        f, fs = (None, 0) if film is None else (film, self.film_total)
+        return ops.group_norm_affine(x, None, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws,
+                                     film=f, film_stride=fs, keep=keep)
+
+    def _res(self, n, L, x, film_all, tape):
+        w = self.w
+        cin, cout, mode = L[1], L[2], L[3]
+        k1 = {} if tape is not None else None
+        k2 = {} if tape is not None else None
+        gn1 = self._gn(x, n + ".in_layers.0", keep=k1)
+        if mode == "down":
+            hp = ops.avgpool2_nhwc(x.t, gn=gn1, silu=True)
+            xs = ops.avgpool2_nhwc(x.t)
+            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+        else:
+            h = ops.conv2d(x, w[n + ".in_layers.2.weight"], cout, 3, gn=gn1, gn_silu=True,
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+            xs = x.t if cin == cout else ops.conv2d(x, w[n + ".skip_connection.weight"], cout, 1,
+                                                    bias=w[n + ".skip_connection.bias"])
+        gn2 = self._gn(h, n + ".out_layers.0", film=film_all[:, self._film_off[n]:], keep=k2)
+        out = ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
+                         bias=w[n + ".out_layers.3.bias"], res=xs, emit_stats=True)
+        if tape is not None:
+            tape.append(("res", n, L, x.t, h.t, k1, k2))
+        return out
+
+    def _attn(self, n, x, tape):
+        w = self.w
+        B, H, W, C = x.t.shape
+        T, hc = H * W, self.head_ch
+        nh = C // hc
+        k = {} if tape is not None else None
+        gn = self._gn(x, n + ".norm", keep=k)
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        flat = qkv.view(-1)
+        S = torch.empty(B * nh, T, T, dtype=torch.float32, device=qkv.device)
+        ops.bgemm(flat, flat[hc:], S, T, T, hc, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
+                  sA=(T * 3 * C, 3 * hc), sB=(T * 3 * C, 3 * hc), sC=(nh * T * T, T * T))
+        ops.softmax_rows_(S, B * nh * T, T, T, 1.0 / math.sqrt(hc))
+        o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
+        ops.bgemm(S, flat[2 * hc:], o, T, hc, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B * nh, inner=nh,
+                  sA=(nh * T * T, T * T), sB=(T * 3 * C, 3 * hc), sC=(T * C, hc))
+        out = ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
+        if tape is not None:
+            tape.append(("attn", n, x.t, qkv, S, k))
+        return out
+
+    def forward(self, x, timesteps, tape=None):
+        """logits [B, 1000]; with `tape` (a list) the activations needed by the backward pass are recorded."""
+        if self.w is None:
+            raise RuntimeError("load_state_dict() must be called before forward()")
+        w = self.w
+        B = x.shape[0]
+        self._workspace(B)
+        L = _lib.lib()
+        t = timesteps.to(device=x.device, dtype=torch.float32).contiguous()
+        emb = ops.timestep_embedding(t, w["time.freq"], order=1)
+        emb = ops.linear(emb, w["time_embed.0.weight"], w["time_embed.0.bias"])
+        emb = ops.linear(emb, w["time_embed.2.weight"], w["time_embed.2.bias"], silu_in=True)
+        film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
+        h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD)
+        for prefix, layers in self._walk():
+            for j, Ld in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if Ld[0] == "conv":
+                    h = ops.conv2d(h, w[n + ".weight"], Ld[2], 3, bias=w[n + ".bias"], emit_stats=True)
+                elif Ld[0] == "res":
+                    h = self._res(n, Ld, h, film_all, tape)
+                else:
+                    h = self._attn(n, h, tape)
+        # out: GroupNorm -> SiLU -> AttentionPool2d
+        kp = {} if tape is not None else None
+        gn = self._gn(h, "out.0", keep=kp)
+        C, HW = self.final_ch, self.pool_sp ** 2
+        T, nh = HW + 1, self.final_ch // self.head_ch
+        X = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+        check(L.ddnm_pool_tokens_f32(_p(h.t), _p(gn[0]), _p(gn[1]), _p(w["pool.pos"]), _p(X), B, HW, C, ops._stream()),
+              "ddnm_pool_tokens_f32")
+        qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
+        ops.bgemm(X, w["pool.qkv.weight"], qkv, B * T, 3 * C, C, lda=C, ldb=C, ldc=3 * C, transb=True,
+                  D=w["pool.qkv.bias"], ldd=0, beta=1.0)
+        P = torch.empty(B, nh, T, dtype=torch.float32, device=x.device)
+        a0 = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        check(L.ddnm_pool_attn_fwd_f32(_p(qkv), _p(P), _p(a0), B, T, C, nh, ops._stream()), "ddnm_pool_attn_fwd_f32")
+        logits = ops.linear(a0, w["pool.c.weight"], w["pool.c.bias"])
+        if tape is not None:
+            tape.append(("pool", h.t, kp, qkv, P))
+        return logits
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------ backward: d log p(y|x,t) / dx
+    def _gn_bwd(self, x, dA, keep, silu, add=None, dA_ups=False, add_ups=False):
+        B, H, W, C = x.shape
+        L = _lib.lib()
+        nchunk = L.ddnm_gn_bwd_nchunk(H * W, C)
+        dx = torch.empty_like(x)
+        check(L.ddnm_gn_bwd_f32(_p(x), _p(dA), int(dA_ups), _p(keep["scale"]), _p(keep["shift"]), _p(keep["mean_rstd"]),
+                                int(silu), _p(add), int(add_ups), B, H, W, C, keep["groups"], _p(self._bwd_partial),
+                                nchunk, _p(self._bwd_coef), _p(dx), ops._stream()), "ddnm_gn_bwd_f32")
+        return dx
+
+    def _res_bwd(self, rec, dout):
+        _, n, L, x, h1, k1, k2 = rec
+        w = self.w
+        cin, cout, mode = L[1], L[2], L[3]
+        da2 = ops.conv2d(dout, w[n + ".out_layers.3.dgrad"], cout, 3)
+        dh1 = self._gn_bwd(h1, da2, k2, True)
+        da1 = ops.conv2d(dh1, w[n + ".in_layers.2.dgrad"], cin, 3)
+        if mode == "down":
+            return self._gn_bwd(x, da1, k1, True, add=dout, dA_ups=True, add_ups=True)
+        skip = dout if cin == cout else ops.conv2d(dout, w[n + ".skip_connection.dgrad"], cin, 1)
+        return self._gn_bwd(x, da1, k1, True, add=skip)
+
+    def _attn_bwd(self, rec, dout):
+        _, n, x, qkv, P, k = rec
+        w = self.w
+        B, H, W, C = x.shape
+        T, hc = H * W, self.head_ch
+        nh = C // hc
+        dO = ops.conv2d(dout, w[n + ".proj_out.dgrad"], C, 1).view(-1)
+        flat = qkv.view(-1)
+        dqkv = torch.empty_like(qkv)
+        dflat = dqkv.view(-1)
+        sq, sp = (T * 3 * C, 3 * hc), (nh * T * T, T * T)
+        # dV = P^T dO
+        ops.bgemm(P, dO, dflat[2 * hc:], T, hc, T, lda=T, ldb=C, ldc=3 * C, transb=False, transa=True, batch=B * nh,
+                  inner=nh, sA=sp, sB=(T * C, hc), sC=sq)
+        # dP = dO V^T ;  dS = scale * P .* (dP - rowsum(dP .* P))
+        dP = torch.empty_like(P)
+        ops.bgemm(dO, flat[2 * hc:], dP, T, T, hc, lda=C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
+                  sA=(T * C, hc), sB=sq, sC=sp)
+        check(_lib.lib().ddnm_softmax_bwd_rows_f32(_p(P), _p(dP), B * nh * T, T, T, 1.0 / math.sqrt(hc), ops._stream()),
+              "ddnm_softmax_bwd_rows_f32")
+        # dQ = dS K ;  dK = dS^T Q
+        ops.bgemm(dP, flat[hc:], dflat, T, hc, T, lda=T, ldb=3 * C, ldc=3 * C, transb=False, batch=B * nh, inner=nh,
+                  sA=sp, sB=sq, sC=sq)
+        ops.bgemm(dP, flat, dflat[hc:], T, hc, T, lda=T, ldb=3 * C, ldc=3 * C, transb=False, transa=True, batch=B * nh,
+                  inner=nh, sA=sp, sB=sq, sC=sq)
+        dn = ops.conv2d(dqkv, w[n + ".qkv.dgrad"], C, 1)
+        return self._gn_bwd(x, dn, k, False, add=dout)
+
+    def log_prob_grad(self, x, timesteps, y):
+        """d/dx log_softmax(classifier(x, t))[y]  as NCHW [B, 3, R, R]."""
+        L = _lib.lib()
+        w = self.w
+        B = x.shape[0]
+        tape = []
+        logits = self.forward(x, timesteps, tape=tape)
+        yy = y.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
+        dlogits = torch.empty_like(logits)
+        check(L.ddnm_logsoftmax_grad_f32(_p(logits), _p(yy), _p(dlogits), B, logits.shape[1], ops._stream()),
+              "ddnm_logsoftmax_grad_f32")
+        # AttentionPool2d backward
+        _, h_pre, kp, qkv, P = tape.pop()
+        C, HW = self.final_ch, self.pool_sp ** 2
+        T, nh = HW + 1, self.final_ch // self.head_ch
+        da0 = ops.linear(dlogits, w["pool.c.weight_t"], None)
+        dqkv = torch.empty_like(qkv)
+        check(L.ddnm_pool_attn_bwd_f32(_p(qkv), _p(P), _p(da0), _p(dqkv), B, T, C, nh, ops._stream()),
+              "ddnm_pool_attn_bwd_f32")
+        dX = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+        ops.bgemm(dqkv, w["pool.qkv.weight"], dX, B * T, C, 3 * C, lda=3 * C, ldb=C, ldc=C, transb=False)
+        dact = torch.empty_like(h_pre)
+        check(L.ddnm_pool_tokens_bwd_f32(_p(dX), _p(dact), B, HW, C, ops._stream()), "ddnm_pool_tokens_bwd_f32")
+        dh = self._gn_bwd(h_pre, dact, kp, True)
+        while tape:
+            rec = tape.pop()
+            dh = self._res_bwd(rec, dh) if rec[0] == "res" else self._attn_bwd(rec, dh)
+        n = "input_blocks.0.0"
+        return ops.conv2d(dh, w[n + ".dgrad"], self.in_channels, 3, out_nchw=True)
+
+
+def make_cond_fn(classifier, classifier_scale):
+    """The `cond_fn` closure of guided_diffusion/diffusion.py:183-189 on the HIP engine."""
+    from .. import ops as _ops
+
+    def cond_fn(x, t, y):
+        g = classifier.log_prob_grad(x, t, y)
+        if classifier_scale != 1.0:
+            from ..functions.svd_operators import _axpby
+            g = _axpby(g, None, float(classifier_scale), 0.0)
+        return g
+    return cond_fn

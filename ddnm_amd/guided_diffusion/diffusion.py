@@ -196,8 +196,26 @@ class Diffusion(object):
                 raise FileNotFoundError(f"{ckpt} not found (no network here: place the checkpoint there, or set "
                                         "DDNM_RANDOM_WEIGHTS=1 for seeded random weights)")
             if cfg.model.class_cond:
-                raise NotImplementedError("classifier guidance (cond_fn over EncoderUNetModel, diffusion.py:166-191) "
-                                          "is the next hot-path row (SURVEY.md section 8 a16)")
+                # noisy classifier + guidance gradient (diffusion.py:166-191)
+                from .classifier import args_to_dict, classifier_defaults, create_classifier, make_cond_fn
+                ckpt = os.path.join(self.args.exp, "logs/imagenet/%dx%d_classifier.pt" % (
+                    cfg.data.image_size, cfg.data.image_size))
+                classifier = create_classifier(**args_to_dict(cfg.classifier, classifier_defaults().keys()))
+                classifier.device = self.device
+                if os.path.exists(ckpt):
+                    classifier.load_state_dict(torch.load(ckpt, map_location="cpu"))
+                elif os.environ.get("DDNM_RANDOM_WEIGHTS") == "1":
+                    g = torch.Generator().manual_seed(self.args.seed + 1)
+                    sd = {k: (torch.randn(v, generator=g) * (1.0 / max(1, int(np.prod(v[1:])))) ** 0.5 if len(v) > 1
+                              else (1.0 + 0.1 * torch.randn(v, generator=g) if k.endswith("weight") else
+                                    0.05 * torch.randn(v, generator=g)))
+                          for k, v in classifier.state_dict_shapes().items()}
+                    classifier.load_state_dict(sd)
+                else:
+                    raise FileNotFoundError(f"{ckpt} not found (set DDNM_RANDOM_WEIGHTS=1 for seeded random weights)")
+                if cfg.classifier.classifier_use_fp16:
+                    classifier.convert_to_fp16()
+                self._cls_fn = make_cond_fn(classifier, cfg.classifier.classifier_scale)
             return model
         raise ValueError(cfg.model.type)
 
@@ -207,10 +225,11 @@ class Diffusion(object):
         print(("Run Simplified DDNM, without SVD." if simplified else "Run SVD-based DDNM."),
               f"{tt.T_sampling} sampling steps.", f"travel_length = {tt.travel_length},",
               f"travel_repeat = {tt.travel_repeat}.", f"Task: {self.args.deg}.")
+        cls_fn = getattr(self, "_cls_fn", None)
         if simplified:
-            self.simplified_ddnm_plus(model, None)
+            self.simplified_ddnm_plus(model, cls_fn)
         else:
-            self.svd_based_ddnm_plus(model, None)
+            self.svd_based_ddnm_plus(model, cls_fn)
 
     # ------------------------------------------------------------------ data
     def _loader(self):

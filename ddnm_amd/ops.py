@@ -183,46 +183,53 @@ def gn_nchunk(hw, c):
     return n
 
 
-def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0):
+def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0, keep=None):
     """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written.
     `film` (rows [s | t], row stride film_stride) folds the FiLM modulation GN(x)*(1+s)+t into the affine.
     src0 / src1 may be tensors or `Act`s; when every source carries conv-epilogue partials the statistics
     come from those (no pass over the activation), otherwise from the stand-alone statistics kernel."""
+    # keep: optional dict that receives private copies of (scale, shift, mean_rstd) for a backward pass
     a0 = src0 if isinstance(src0, Act) else Act(src0)
     a1 = None if src1 is None else (src1 if isinstance(src1, Act) else Act(src1))
     src0, src1 = a0.t, (None if a1 is None else a1.t)
     B, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]
     C, HW = C0 + C1, H * W
+    sc_buf, sh_buf, mr = ws.scale, ws.shift, None
+    if keep is not None:
+        sc_buf = torch.empty(B * C, dtype=torch.float32, device=src0.device)
+        sh_buf = torch.empty(B * C, dtype=torch.float32, device=src0.device)
+        mr = torch.empty(B * groups * 2, dtype=torch.float32, device=src0.device)
+        keep.update(scale=sc_buf, shift=sh_buf, mean_rstd=mr, groups=groups)
     if a0.stats is not None and (a1 is None or a1.stats is not None):
-        if ws.scale.numel() < B * C:
+        if sc_buf.numel() < B * C:
             raise ValueError("GroupNorm workspace too small")
         check(_lib.lib().ddnm_gn_finalize_tiles_f32(_p(a0.stats), a0.tiles, C0, None if a1 is None else _p(a1.stats),
                                                     0 if a1 is None else a1.tiles, C1, _p(gamma), _p(beta), B, HW,
-                                                    groups, eps, _p(ws.scale), _p(ws.shift), _p(film), film_stride,
-                                                    _stream()), "ddnm_gn_finalize_tiles_f32")
-        return ws.scale, ws.shift
+                                                    groups, eps, _p(sc_buf), _p(sh_buf), _p(film), film_stride,
+                                                    _p(mr), _stream()), "ddnm_gn_finalize_tiles_f32")
+        return sc_buf, sh_buf
     nchunk = gn_nchunk(HW, C)
     need = B * nchunk * groups * 2
-    if ws.partial.numel() < need or ws.scale.numel() < B * C:
+    if ws.partial.numel() < need or sc_buf.numel() < B * C:
         raise ValueError("GroupNorm workspace too small")
     L = _lib.lib()
     check(L.ddnm_gn_stats_f32(_p(src0), _p(src1), B, HW, C0, C1, groups, _p(ws.partial), nchunk, _stream()),
           "ddnm_gn_stats_f32")
-    check(L.ddnm_gn_finalize_f32(_p(ws.partial), nchunk, _p(gamma), _p(beta), B, HW, C, groups, eps, _p(ws.scale),
-                                 _p(ws.shift), _p(film), film_stride, _stream()), "ddnm_gn_finalize_f32")
-    return ws.scale, ws.shift
+    check(L.ddnm_gn_finalize_f32(_p(ws.partial), nchunk, _p(gamma), _p(beta), B, HW, C, groups, eps, _p(sc_buf),
+                                 _p(sh_buf), _p(film), film_stride, _p(mr), _stream()), "ddnm_gn_finalize_f32")
+    return sc_buf, sh_buf
 
 
 # ----------------------------------------------------------------------------- GEMM / softmax / linear
 def bgemm(A, Bm, C, M, N, K, *, lda, ldb, ldc, transb, batch=1, inner=1, sA=(0, 0), sB=(0, 0), sC=(0, 0),
-          D=None, ldd=0, sD=(0, 0), alpha=1.0, beta=0.0):
+          D=None, ldd=0, sD=(0, 0), alpha=1.0, beta=0.0, transa=False):
     d = GemmDesc()
     d.A, d.Bm, d.D, d.C = _p(A), _p(Bm), _p(D), _p(C)
     d.M, d.N, d.K, d.lda, d.ldb, d.ldc, d.ldd = M, N, K, lda, ldb, ldc, ldd
     d.transb, d.batch, d.inner = int(transb), batch, inner
     d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi, d.sDo, d.sDi = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sD[0], sD[1]
-    d.alpha, d.beta = alpha, beta
+    d.alpha, d.beta, d.transa = alpha, beta, int(transa)
     check(_lib.lib().ddnm_bgemm_f32(ctypes.byref(d), _stream()), "ddnm_bgemm_f32")
     return C
 

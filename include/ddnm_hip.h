@@ -111,14 +111,15 @@ int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gam
                          int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
                          float* scale /* [B][C] */, float* shift /* [B][C] */,
                          const float* film /* optional FiLM rows [s(0..C) | t(0..C)]: GN(x)*(1+s)+t, unet.py:248-251 */,
-                         int32_t film_stride, void* stream);
+                         int32_t film_stride, float* mean_rstd /* optional [B][groups][2], kept for backward */,
+                         void* stream);
 
 /* GroupNorm affine from the partials a convolution epilogue emitted (`stats_out`); the input may be the
  * channel concat of two tensors (part1 / tpi1 / C1, or NULL / 0 / 0). */
 int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tiles_per_img0, int32_t C0, const float* part1,
                                int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
                                int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,
-                               int32_t film_stride, void* stream);
+                               int32_t film_stride, float* mean_rstd, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batched GEMM on MFMA f32:  C = alpha * A * op(B) + beta * D
@@ -137,8 +138,34 @@ typedef struct ddnm_gemm_desc {
     int32_t batch, inner;                 /* batch = outer*inner */
     int64_t sAo, sAi, sBo, sBi, sCo, sCi, sDo, sDi;   /* element strides */
     float alpha, beta;
+    int32_t transa;                       /* 1: A stored [K][M] (lda = pitch of that storage) */
+    int32_t reserved;
 } ddnm_gemm_desc;
 int ddnm_bgemm_f32(const ddnm_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Input-gradient path of classifier guidance (guided_diffusion/diffusion.py:183-189 through
+ * EncoderUNetModel, unet.py:684-895): only activation gradients are needed.
+ * ------------------------------------------------------------------------- */
+/* GroupNorm(+FiLM)(+SiLU) backward: dx = dL/dx for a = act(x*gn_scale + gn_shift); dA may sit behind a 2x2
+ * average pool (dA_ups: [B][H/2][W/2][C], x0.25); `add` (same optional mapping) is summed in (skip branch). */
+int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, const float* gn_scale, const float* gn_shift,
+                    const float* mean_rstd, int32_t silu, const float* add, int32_t add_ups, int32_t B, int32_t H,
+                    int32_t W, int32_t C, int32_t groups, double* partial /* [B][nchunk][groups][2] */, int32_t nchunk,
+                    float* coef /* [B][groups][2] */, float* dx, void* stream);
+int ddnm_gn_bwd_nchunk(int32_t HW, int32_t C);
+/* in place on dP: dS = scale * P .* (dP - rowsum(dP .* P)) */
+int ddnm_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);
+/* AttentionPool2d (unet.py:22-51): tokens, class-token attention (new qkv order), their backward, and the
+ * gradient of log_softmax(logits)[y]. */
+int ddnm_pool_tokens_f32(const float* h, const float* gn_scale, const float* gn_shift, const float* pos /* [C][HW+1] */,
+                         float* X /* [B][HW+1][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
+int ddnm_pool_attn_fwd_f32(const float* qkv /* [B][T][3C] */, float* P /* [B][heads][T] */, float* a0 /* [B][C] */,
+                           int32_t B, int32_t T, int32_t C, int32_t heads, void* stream);
+int ddnm_pool_attn_bwd_f32(const float* qkv, const float* P, const float* da0, float* dqkv, int32_t B, int32_t T,
+                           int32_t C, int32_t heads, void* stream);
+int ddnm_pool_tokens_bwd_f32(const float* dX, float* dact /* [B][HW][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
+int ddnm_logsoftmax_grad_f32(const float* logits, const int64_t* y, float* dlogits, int32_t B, int32_t N, void* stream);
 
 /* Row softmax in place: x[r][0..n) <- softmax(scale * x[r][:]); rows contiguous with ld. */
 int ddnm_softmax_rows_f32(float* x, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);
@@ -212,6 +239,9 @@ int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_next, int64_
 /* ---- DDNM+ (sigma_y > 0, functions/svd_ddnm.py:80-164) building blocks --------------------------------- */
 /* out = a*x + b*y (y may be NULL) */
 int ddnm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream);
+/* out[b][i] = a*x[b*x_bstride + i] + b*y[b*chw + i]  (guided eps: eps[:, :3] - sqrt(1-abar)*grad, svd_ddnm.py:51-52) */
+int ddnm_axpby_strided_f32(const float* x, int64_t x_bstride, const float* y, float* out, int32_t B, int64_t chw,
+                           float a, float b, void* stream);
 /* out = (m ? cx_m : cx_n)*x + (m ? cy_m : cy_n)*y with m = mask[plane % planes_mask][p] != 0 (mask NULL: all measured):
  * Lambda / Lambda_noise of Inpainting (svd_operators.py:361-439), spectral weights of WalshHadamardCS (:253-320). */
 int ddnm_mask_mix_f32(const float* x, const float* y, const float* mask, int32_t planes_mask, int64_t plane_elems,

@@ -268,3 +268,86 @@ def adm_shapes(config):
 def adm_state_dict(config, seed=1234):
     """Every tensor random -- including the zero_module'd ones (nn.py:68), else eps == 0 identically."""
     return fill(adm_shapes(config), seed)
+
+
+# ----------------------------------------------------------------------------------------------
+# Noisy classifier (guided_diffusion/unet.py::EncoderUNetModel via script_util.create_classifier)
+# ----------------------------------------------------------------------------------------------
+def classifier_config(image_size=256, classifier_width=128, classifier_depth=2,
+                      classifier_attention_resolutions="32,16,8", classifier_scale=1.0):
+    """Keys of configs/imagenet_256_cc.yml:36-45 (classifier_use_fp16 False: the oracle runs fp32)."""
+    return types.SimpleNamespace(image_size=image_size, classifier_use_fp16=False, classifier_width=classifier_width,
+                                 classifier_depth=classifier_depth,
+                                 classifier_attention_resolutions=classifier_attention_resolutions,
+                                 classifier_use_scale_shift_norm=True, classifier_resblock_updown=True,
+                                 classifier_pool="attention", classifier_scale=classifier_scale)
+
+
+def classifier_blocks(cc):
+    """input_blocks / middle_block of EncoderUNetModel.__init__ (unet.py:737-815) as plain data (cf. adm_blocks)."""
+    mult = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4),
+            32: (1, 2)}[cc.image_size]      # 32: reduced test size only
+    mc = cc.classifier_width
+    attn_ds = tuple(cc.image_size // int(r) for r in cc.classifier_attention_resolutions.split(","))
+    ch = int(mult[0] * mc)
+    inp = [[("conv", 3, ch)]]
+    ds = 1
+    for level, mu in enumerate(mult):
+        for _ in range(cc.classifier_depth):
+            layers = [("res", ch, int(mu * mc), "")]
+            ch = int(mu * mc)
+            if ds in attn_ds:
+                layers.append(("attn", ch))
+            inp.append(layers)
+        if level != len(mult) - 1:
+            inp.append([("res", ch, ch, "down")])
+            ds *= 2
+    mid = [("res", ch, ch, ""), ("attn", ch), ("res", ch, ch, "")]
+    return inp, mid, ch, cc.image_size // ds
+
+
+def classifier_shapes(cc):
+    mc = cc.classifier_width
+    ted = 4 * mc
+    s = OrderedDict()
+    _lin(s, "time_embed.0", ted, mc)
+    _lin(s, "time_embed.2", ted, ted)
+
+    def layer(prefix, L):
+        if L[0] == "conv":
+            _conv(s, prefix, L[2], L[1], 3)
+        elif L[0] == "res":
+            _, cin, cout, _mode = L
+            _gn(s, prefix + ".in_layers.0", cin)
+            _conv(s, prefix + ".in_layers.2", cout, cin, 3)
+            _lin(s, prefix + ".emb_layers.1", 2 * cout, ted)
+            _gn(s, prefix + ".out_layers.0", cout)
+            _conv(s, prefix + ".out_layers.3", cout, cout, 3)
+            if cin != cout:
+                _conv(s, prefix + ".skip_connection", cout, cin, 1)
+        else:
+            c = L[1]
+            _gn(s, prefix + ".norm", c)
+            s[prefix + ".qkv.weight"], s[prefix + ".qkv.bias"] = (3 * c, c, 1), (3 * c,)
+            s[prefix + ".proj_out.weight"], s[prefix + ".proj_out.bias"] = (c, c, 1), (c,)
+
+    inp, mid, ch, sp = classifier_blocks(cc)
+    for i, layers in enumerate(inp):
+        for j, L in enumerate(layers):
+            layer(f"input_blocks.{i}.{j}", L)
+    for j, L in enumerate(mid):
+        layer(f"middle_block.{j}", L)
+    _gn(s, "out.0", ch)
+    s["out.2.positional_embedding"] = (ch, sp * sp + 1)
+    s["out.2.qkv_proj.weight"], s["out.2.qkv_proj.bias"] = (3 * ch, ch, 1), (3 * ch,)
+    s["out.2.c_proj.weight"], s["out.2.c_proj.bias"] = (1000, ch, 1), (1000,)
+    return s
+
+
+def classifier_state_dict(cc, seed=4321):
+    shapes = classifier_shapes(cc)
+    sd = fill(shapes, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    pe = shapes["out.2.positional_embedding"]
+    sd["out.2.positional_embedding"] = (torch.randn(pe, generator=g) / pe[0] ** 0.5).contiguous()
+    return sd

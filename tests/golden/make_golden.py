@@ -66,6 +66,44 @@ def sub(t, step=8):
     return t[..., ::step, ::step].contiguous().numpy()
 
 
+def make_classifier():
+    """EncoderUNetModel (create_classifier) of the reference + the cond_fn gradient of diffusion.py:183-189
+    (torch autograd), fp32, seeded weights: key list, logits and input gradients at three sizes."""
+    import torch.nn.functional as F
+    from oracle import weights
+    ns = ref_import.load()
+    out = {}
+    for kind, kw in (("small", dict(image_size=32, classifier_depth=1, classifier_attention_resolutions="16,8")),
+                     ("mid", dict(image_size=64, classifier_depth=1)), ("full", dict())):
+        cc = weights.classifier_config(**kw)
+        if cc.image_size == 32:       # create_classifier has no 32-px table; same class, built directly
+            ref = ns.unet.EncoderUNetModel(image_size=32, in_channels=3, model_channels=128, out_channels=1000,
+                                           num_res_blocks=1, attention_resolutions=(2, 4), channel_mult=(1, 2),
+                                           use_fp16=False, num_head_channels=64, use_scale_shift_norm=True,
+                                           resblock_updown=True, pool="attention")
+        else:
+            ref = ns.script_util.create_classifier(**{k: getattr(cc, k) for k in ns.script_util.classifier_defaults()})
+        if kind == "full":
+            json.dump([[k, list(v.shape)] for k, v in ref.state_dict().items()],
+                      open(os.path.join(HERE, "classifier_state_dict_keys.json"), "w"))
+        ref.load_state_dict(weights.classifier_state_dict(cc))
+        ref.eval()
+        g = torch.Generator().manual_seed(cases.SEED + 11)
+        r = cc.image_size
+        x = torch.randn(2, 3, r, r, generator=g)
+        t = torch.tensor([430.0, 10.0])
+        y = torch.tensor([951, 17])
+        with torch.enable_grad():
+            xin = x.detach().requires_grad_(True)
+            logits = ref(xin, t)
+            sel = F.log_softmax(logits, dim=-1)[range(2), y]
+            grad = torch.autograd.grad(sel.sum(), xin)[0]
+        out[f"{kind}_logits"] = logits.detach().numpy()
+        out[f"{kind}_grad"] = grad.numpy() if kind != "full" else sub(grad, 4)
+        out[f"{kind}_grad_norm"] = np.array([grad.double().norm().item()])
+    np.savez_compressed(os.path.join(HERE, "classifier.npz"), **out)
+
+
 def make_deblur():
     """Deblurring / Deblurring2D of the reference: A, A_pinv at 64^2 and one 12-step sampler run (small net)."""
     ns = ref_import.load()
@@ -159,7 +197,10 @@ def main():
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
+    ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     args = ap.parse_args()
+    if args.classifier_only:
+        return make_classifier()
     if args.deblur_only:
         return make_deblur()
     if args.adm_only:

@@ -48,7 +48,7 @@ def test_struct_layouts_match_header():
     # 9 pointers + 16 int32 + pointer + int64 + 2 int32 + pointer (8-byte aligned)
     assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8 + 8 + 8
     assert ConvDesc.workspace.offset == 9 * 8 + 16 * 4
-    assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4
+    assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4 + 2 * 4
     assert ctypes.sizeof(StepScalars) == 24
     src = open(HEADER).read()
     conv = src[src.index("typedef struct ddnm_conv_desc"):src.index("} ddnm_conv_desc;")]

@@ -1,0 +1,159 @@
+"""Classifier guidance (BASELINE config 5): oracle restatement (torch autograd on CPU) pinned to goldens of the
+reference's EncoderUNetModel + cond_fn; HIP engine forward and explicit backward against both."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, classifier as OC, weights
+from tests.helpers import rel
+
+KINDS = {"small": dict(image_size=32, classifier_depth=1, classifier_attention_resolutions="16,8"),
+         "mid": dict(image_size=64, classifier_depth=1), "full": dict()}
+
+
+def _inputs(r):
+    g = torch.Generator().manual_seed(cases.SEED + 11)
+    return torch.randn(2, 3, r, r, generator=g), torch.tensor([430.0, 10.0]), torch.tensor([951, 17])
+
+
+def _engine(cc, sd):
+    from ddnm_amd.guided_diffusion.classifier import EncoderUNetModel
+    mult = {256: (1, 1, 2, 2, 4, 4), 64: (1, 2, 3, 4), 32: (1, 2)}[cc.image_size]
+    ads = tuple(cc.image_size // int(r) for r in cc.classifier_attention_resolutions.split(","))
+    m = EncoderUNetModel(image_size=cc.image_size, in_channels=3, model_channels=cc.classifier_width, out_channels=1000,
+                         num_res_blocks=cc.classifier_depth, attention_resolutions=ads, channel_mult=mult,
+                         num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True, pool="attention")
+    m.load_state_dict(sd)
+    return m
+
+
+def test_classifier_keys_golden(golden_dir):
+    keys = json.load(open(f"{golden_dir}/classifier_state_dict_keys.json"))
+    mine = weights.classifier_shapes(weights.classifier_config())
+    assert [[k, list(v)] for k, v in mine.items()] == keys
+    assert sum(int(np.prod(v)) for v in mine.values()) == 54_096_360          # 54.10 M
+    from ddnm_amd.guided_diffusion.classifier import classifier_defaults, create_classifier
+    cc = weights.classifier_config()
+    eng = create_classifier(**{k: getattr(cc, k) for k in classifier_defaults()})
+    assert [[k, list(v)] for k, v in eng.state_dict_shapes().items()] == keys
+
+
+@pytest.mark.parametrize("kind", ["small", "mid"])
+def test_oracle_classifier_golden(kind, golden_dir):
+    g = np.load(f"{golden_dir}/classifier.npz")
+    cc = weights.classifier_config(**KINDS[kind])
+    sd = weights.classifier_state_dict(cc)
+    x, t, y = _inputs(cc.image_size)
+    with torch.no_grad():
+        logits = OC.forward(sd, cc, x, t)
+    assert torch.equal(logits, torch.from_numpy(g[f"{kind}_logits"]))
+    grad = OC.cond_fn(sd, cc, x, t, y)
+    assert rel(grad, torch.from_numpy(g[f"{kind}_grad"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["small", "mid", "full"])
+def test_engine_classifier_logits_and_gradient(hip, kind, golden_dir):
+    g = np.load(f"{golden_dir}/classifier.npz")
+    cc = weights.classifier_config(**KINDS[kind])
+    sd = weights.classifier_state_dict(cc)
+    x, t, y = _inputs(cc.image_size)
+    m = _engine(cc, sd)
+    logits = m(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    assert rel(logits, torch.from_numpy(g[f"{kind}_logits"])) < 2e-5
+    grad = m.log_prob_grad(x.cuda(), t.cuda(), y.cuda()).cpu()
+    ref = torch.from_numpy(g[f"{kind}_grad"])
+    got = grad if kind != "full" else grad[..., ::4, ::4]
+    assert got.shape == ref.shape
+    assert rel(got, ref) < 2e-4
+    assert abs(grad.double().norm().item() - float(g[f"{kind}_grad_norm"][0])) < 2e-4 * float(g[f"{kind}_grad_norm"][0])
+
+
+@pytest.mark.gpu
+def test_gn_backward_kernel(hip):
+    """GroupNorm(+FiLM)+SiLU backward against torch autograd on CPU, incl. the half-resolution (avg-pool) mapping."""
+    import torch.nn.functional as F
+    from ddnm_amd import _lib, ops
+    from ddnm_amd._lib import check
+    gen = torch.Generator().manual_seed(2)
+    B, C, H = 2, 128, 16
+    x = torch.randn(B, C, H, H, generator=gen, requires_grad=True)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen)
+    dA_half = torch.randn(B, C, H // 2, H // 2, generator=gen)
+    add_half = torch.randn(B, C, H // 2, H // 2, generator=gen)
+    a = F.avg_pool2d(F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5)), 2, 2)
+    (a * dA_half).sum().backward()
+    ref = x.grad + F.interpolate(add_half, scale_factor=2, mode="nearest") * 0.25
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()      # noqa: E731
+    ws = ops.GroupNormWorkspace("cuda", B, C, B * ops.gn_nchunk(H * H, C) * 64)
+    keep = {}
+    ops.group_norm_affine(nh(x), None, gamma.cuda(), beta.cuda(), 1e-5, ws, keep=keep)
+    L = _lib.lib()
+    nchunk = L.ddnm_gn_bwd_nchunk(H * H, C)
+    partial = torch.empty(B * nchunk * 64, dtype=torch.float64, device="cuda")
+    coef = torch.empty(B * 64, device="cuda")
+    dx = torch.empty(B, H, H, C, device="cuda")
+    xa, da, ad = nh(x), nh(dA_half), nh(add_half)
+    check(L.ddnm_gn_bwd_f32(xa.data_ptr(), da.data_ptr(), 1, keep["scale"].data_ptr(), keep["shift"].data_ptr(),
+                            keep["mean_rstd"].data_ptr(), 1, ad.data_ptr(), 1, B, H, H, C, 32, partial.data_ptr(), nchunk,
+                            coef.data_ptr(), dx.data_ptr(), ops._stream()), "gn_bwd")
+    torch.cuda.synchronize()
+    assert rel(dx.cpu().permute(0, 3, 1, 2), ref) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(64, 64, 256), (256, 64, 1024), (16, 24, 40)])
+def test_bgemm_transposed_a(hip, M, N, K):
+    from ddnm_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    A = torch.randn(3, K, M, generator=gen)
+    Bm = torch.randn(3, K, N, generator=gen)
+    C = torch.empty(3, M, N, device="cuda")
+    ops.bgemm(A.cuda(), Bm.cuda(), C, M, N, K, lda=M, ldb=N, ldc=N, transb=False, transa=True, batch=3,
+              sA=(K * M, 0), sB=(K * N, 0), sC=(M * N, 0))
+    torch.cuda.synchronize()
+    assert rel(C.cpu(), torch.bmm(A.transpose(1, 2), Bm)) < 2e-6
+
+
+@pytest.mark.gpu
+def test_guided_sampler_small(hip):
+    """ddnm_diffusion with a class-conditional ADM net + cls_fn (reference quirks: class 951 for every image,
+    guidance evaluated on the INITIAL noise) against the oracle loop with the oracle cond_fn."""
+    from ddnm_amd.functions.svd_ddnm import class_num, ddnm_diffusion
+    from ddnm_amd.guided_diffusion.classifier import make_cond_fn
+    from ddnm_amd.guided_diffusion.unet import create_model
+    from oracle import schedule, unet_adm
+    from tests.helpers import engine_operator
+    cfg, sd = cases.adm_net("small")                       # class-conditional, 32 px
+    cc = weights.classifier_config(**KINDS["small"])
+    csd = weights.classifier_state_dict(cc)
+    cfg.time_travel.T_sampling = 6
+    x_orig, x_T, tape = cases.sampler_case(cfg, 2, 6)
+    orc = cases.make_operator("cs_walshhadamard", 32)
+    y = orc.A(x_orig)
+    betas = cases.betas()
+    # oracle loop (functions/svd_ddnm.py:41-65 with cls_fn)
+    net = unet_adm.Net(sd, cfg)
+    xt, x0 = x_T.clone(), None
+    cls = torch.full((2,), class_num, dtype=torch.long)
+    times = schedule.jump_times(6, 1, 1)
+    skip = 1000 // 6
+    for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
+        i, j = i * skip, (j * skip if j >= 0 else -1)
+        at, atn = schedule.alpha_bar(betas, i), schedule.alpha_bar(betas, j)
+        t = torch.ones(2) * i
+        et = net(xt, t, cls)[:, :3]
+        et = et - (1 - at).sqrt() * OC.cond_fn(csd, cc, x_T, t, cls)
+        x0 = (xt - et * (1 - at).sqrt()) / at.sqrt()
+        x0h = x0 - orc.A_pinv(orc.A(x0.reshape(2, -1)) - y).reshape(x0.shape)
+        xt = atn.sqrt() * x0h + (1 - atn).sqrt() * 0.85 * tape[k] + (1 - atn).sqrt() * ((1 - 0.85 ** 2) ** 0.5) * et
+    model = create_model(**vars(cfg.model))
+    model.load_state_dict(sd)
+    clf = _engine(cc, csd)
+    xs, _ = ddnm_diffusion(x_T.cuda(), model, betas.cuda(), 0.85, engine_operator("cs_walshhadamard", 32), y.cuda(),
+                           cls_fn=make_cond_fn(clf, 1.0), classes=None, config=cfg, noise=[n.cuda() for n in tape])
+    torch.cuda.synchronize()
+    assert rel(xs[0], xt) < 2e-4
