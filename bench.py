@@ -106,7 +106,8 @@ def bench_adm(args, ddist, rank, world, dev):
     (552.81 M params, 2242.87 GFLOP per forward per image), fp16-operand MFMA torso."""
     import types
     from ddnm_amd.functions.svd_ddnm import ddnm_diffusion, get_schedule_jump
-    from ddnm_amd.functions.svd_operators import Colorization, Inpainting
+    from ddnm_amd.functions.svd_operators import Colorization, Inpainting, WalshHadamardCS
+    from ddnm_amd.guided_diffusion.classifier import classifier_defaults, create_classifier, make_cond_fn
     from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
     from ddnm_amd.guided_diffusion.unet import create_model
     ns = types.SimpleNamespace
@@ -115,17 +116,31 @@ def bench_adm(args, ddist, rank, world, dev):
              time_travel=ns(T_sampling=T_SAMPLING, travel_length=travel[0], travel_repeat=travel[1]))
     model = create_model(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8",
                          num_head_channels=64, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
-                         use_fp16=True)
+                         use_fp16=True, class_cond=(args.workload == "c5"))
     model.device = dev
     model.load_state_dict(model.random_state_dict(1234))
     model.convert_to_fp16()
+    cls_fn = None
+    if args.workload == "c5":
+        kw = classifier_defaults()
+        kw["image_size"] = 256
+        clf = create_classifier(**kw)
+        clf.device = dev
+        gsd = torch.Generator().manual_seed(4321)
+        clf.load_state_dict({k: (torch.randn(v, generator=gsd) * (1.0 / max(1, int(torch.tensor(v[1:]).prod()))) ** 0.5
+                                 if len(v) > 1 else (1.0 + 0.1 * torch.randn(v, generator=gsd) if k.endswith("weight")
+                                                     else 0.05 * torch.randn(v, generator=gsd)))
+                             for k, v in clf.state_dict_shapes().items()})
+        cls_fn = make_cond_fn(clf, 1.0)
     betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
                                                num_diffusion_timesteps=1000)).float().to(dev)
-    B = 4
+    B = 8 if args.workload == "c5" else 4
     g = torch.Generator().manual_seed(1234 + rank)
     x_orig = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
     if args.workload == "c3":
         op = Colorization(256, dev)
+    elif args.workload == "c5":
+        op = WalshHadamardCS(3, 256, 4, torch.randperm(256 * 256, generator=g), dev)
     else:
         mask = (torch.rand(256, 256, generator=g) > 0.26).long().reshape(-1)        # 74 % kept, like exp/inp_masks/mask.npy
         r = torch.nonzero(mask == 0).long().reshape(-1) * 3
@@ -136,7 +151,7 @@ def bench_adm(args, ddist, rank, world, dev):
 
     def one_pass():
         x_T = torch.randn(B, 3, 256, 256, device=dev)
-        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=cls_fn, classes=None, config=cfg)
         return ddist.gather_images(xs[0])
 
     for _ in range(args.warmup):
@@ -154,14 +169,17 @@ def bench_adm(args, ddist, rank, world, dev):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = tmax.item()
     value = args.steps * B * world / dt
-    tfl = value * nfe * 2242.87e9 / 1e12 / world
+    tfl = value * nfe * (2243.9e9 + 300e9 if args.workload == "c5" else 2242.87e9) / 1e12 / world
     line = {"metric": "restored images/sec @256x256, 100 DDIM steps", "value": round(value, 4), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": {"c3": "imagenet_256.yml colorization, T_sampling=100, batch 4 per GPU (BASELINE configs[2] shard)",
                                     "c4": "imagenet_256.yml inpainting, time-travel l=10 r=3 (280 NFE + 180 re-noise), "
-                                          "batch 4 per GPU (BASELINE configs[3] shard)"}[args.workload],
+                                          "batch 4 per GPU (BASELINE configs[3] shard)",
+                                    "c5": "imagenet_256_cc.yml cs_walshhadamard ratio 0.25, class-conditional ADM + classifier "
+                                          "guidance (class 951, scale 1.0; classifier fwd + input-gradient in fp32), batch 8 "
+                                          "on 1 GPU (BASELINE configs[4])"}[args.workload],
                        "global_batch": B * world, "nfe_per_image": nfe},
             "whole_loop_tflops_per_gpu": round(tfl, 1), "finite": bool(torch.isfinite(out).all())}
     if rank == 0:
@@ -176,10 +194,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, headline): celeba_hq sr_bicubic 4x B=8/GPU, fp32.  Informational extras: "
                          "c3 = imagenet_256 colorization B=4/GPU, c4 = imagenet_256 inpainting with time travel "
-                         "l=10 r=3 B=4/GPU (ADM UNet, fp16-operand torso like the reference's use_fp16)")
+                         "l=10 r=3 B=4/GPU, c5 = imagenet_256_cc cs_walshhadamard 0.25 + classifier guidance "
+                         "B=8 (ADM UNet, fp16-operand torso like the reference's use_fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -92,3 +92,31 @@ def test_simplified_loop_vs_oracle(hip, deg, sigma_y, golden_dir, tmp_path, monk
                           noise=[n.cuda() for n in tape])
     torch.cuda.synchronize()
     assert rel(got, ref) < 2e-4
+
+
+def test_main_cli_class_conditional_with_classifier_guidance(hip, tmp_path, monkeypatch, capsys):
+    """imagenet_256_cc-style run (reduced to 64 px): class-conditional ADM net (fp16 torso), noisy classifier,
+    cond_fn gradient, cs_walshhadamard -- the whole BASELINE-config-5 plumbing through main.py."""
+    import yaml
+    import main
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "imagenet_256_cc.yml")))
+    cfg["data"]["image_size"] = 64
+    cfg["model"]["image_size"] = 64
+    cfg["model"]["num_channels"] = 128
+    cfg["model"]["attention_resolutions"] = "16,8"
+    cfg["classifier"]["image_size"] = 64
+    cfg["classifier"]["classifier_depth"] = 1
+    cfg["classifier"]["classifier_attention_resolutions"] = "16,8"
+    cfg["time_travel"]["T_sampling"] = 3
+    cfg["sampling"]["batch_size"] = 2
+    os.makedirs(tmp_path / "configs", exist_ok=True)
+    with open(tmp_path / "configs" / "mini_cc.yml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("DDNM_RANDOM_WEIGHTS", "1")
+    rc = main.main(["--ni", "--config", "mini_cc.yml", "--path_y", "synthetic:2", "--eta", "0.85", "--deg",
+                    "cs_walshhadamard", "--deg_scale", "0.25", "--sigma_y", "0.", "-i", "cc"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Total Average PSNR" in out and "Number of samples: 2" in out, out
