@@ -27,6 +27,8 @@ class ConvDesc(Structure):
         ("workspace", c_void_p), ("workspace_floats", c_int64),
         ("res_ups", c_int32), ("reserved", c_int32),
         ("stats_out", c_void_p),
+        ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
+        ("SC0", c_int32), ("SC1", c_int32),
     ]
 
 
@@ -56,6 +58,7 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv2d_f32_fuses_skip": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                              c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
                                              c_void_p, c_void_p]),

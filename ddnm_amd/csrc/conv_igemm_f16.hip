@@ -94,13 +94,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         for (int i = 0; i < BR; ++i)
             b_st[i] = *reinterpret_cast<const uint4*>(wp + (size_t)(BROWS_PER_PASS * i) * 9 * p.Cin);
     };
-    auto stage_halo = [&]() {
+    auto stage_halo = [&](bool apply_gn = true) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int row = prow + HROWS_PER_PASS * i;
             if (row < MAXH) {
                 f32x4 v = h_st[i];
-                if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+                if (apply_gn && has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
                 half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                 *reinterpret_cast<half4*>(&Hs[row * LDH + c4 * 4]) = h;
             }
@@ -175,6 +175,37 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             }
         }
     }
+    // ---- fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's
+    // raw input at the centre tap (see conv_igemm_f32.hip)
+    if (d.skip0 != nullptr && slice == 0) {
+        const int SCin = d.SC0 + d.SC1, nsk = SCin / KC16;
+        const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin + c8 * 8;
+        auto prefetch_skip = [&](int ch) {
+            const int cb = ch * KC16;
+            const float* src;
+            int cs, coff;
+            if (cb < d.SC0) { src = d.skip0; cs = d.SC0; coff = cb; }
+            else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
+                h_st[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i)
+                b_st[i] = *reinterpret_cast<const uint4*>(swbase + (size_t)(BROWS_PER_PASS * i) * SCin + cb);
+        };
+        prefetch_skip(0);
+        for (int ch = 0; ch < nsk; ++ch) {
+            __syncthreads();
+            stage_halo(false);
+            stage_b(0);
+            __syncthreads();
+            if (ch + 1 < nsk) prefetch_skip(ch + 1);
+            mfma_tap(4, 0);
+        }
+    }
     conv_epilogue<WM, WN, MT, NT, true>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
 }
 
@@ -234,6 +265,10 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     PlanF16 pl;
     if (!plan_f16(d, &pl)) return DDNM_E_SHAPE;
+    if (d->skip0) {
+        if (d->ups || !d->skip_weight || d->SC0 <= 0 || d->SC0 % KC16 || d->SC1 % KC16 || (d->SC1 > 0 && !d->skip1))
+            return DDNM_E_SHAPE;
+    }
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
         if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;

@@ -114,14 +114,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 #pragma unroll
         for (int i = 0; i < BR; ++i) b_st[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * 9 * p.Cin);
     };
-    auto stage_halo = [&]() {
+    auto stage_halo = [&](bool apply_gn = true) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             const int row = prow + 32 * i;
             if (row < MAXH) {
                 f32x4 v = h_st[i];
 #ifndef DDNM_PROBE_NO_GN
-                if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+                if (apply_gn && has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
 #endif
                 *reinterpret_cast<f32x4*>(&Hs[row * LDT + c4 * 4]) = v;
             }
@@ -222,6 +222,37 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         }
     }
 #endif
+    // ---- fused 1x1 shortcut (nin_shortcut / skip_connection of a residual block): extra K chunks that read
+    // the block's RAW input (no GroupNorm) at the centre tap and accumulate into the same tile, so the
+    // shortcut needs neither its own launch nor an HBM round trip of its output.
+    if (d.skip0 != nullptr && slice == 0) {
+        const int SCin = d.SC0 + d.SC1, nsk = SCin / KC;
+        const float* swbase = d.skip_weight + (size_t)(n_tile * BN + prow) * SCin + c4 * 4;
+        auto prefetch_skip = [&](int ch) {
+            const int cb = ch * KC;
+            const float* src;
+            int cs, coff;
+            if (cb < d.SC0) { src = d.skip0; cs = d.SC0; coff = cb; }
+            else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
+#pragma unroll
+            for (int i = 0; i < HR; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
+                h_st[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BR; ++i) b_st[i] = *reinterpret_cast<const f32x4*>(swbase + (size_t)(32 * i) * SCin + cb);
+        };
+        prefetch_skip(0);
+        for (int ch = 0; ch < nsk; ++ch) {
+            __syncthreads();
+            stage_halo(false);
+            stage_b(0);
+            __syncthreads();
+            if (ch + 1 < nsk) prefetch_skip(ch + 1);
+            mfma_tap(4, 0);                      // centre tap: the tile's own pixels
+        }
+    }
     conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, Hs);
 }
 
@@ -389,6 +420,12 @@ extern "C" int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d) {
     return pl.BN;
 }
 
+extern "C" int ddnm_conv2d_f32_fuses_skip(const ddnm_conv_desc* d) {
+    ConvPlan pl;
+    if (!d || !make_plan(d, &pl)) return 0;
+    return pl.halo && !d->ups ? 1 : 0;
+}
+
 extern "C" int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d) {
     ConvPlan pl;
     if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
@@ -421,6 +458,11 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     ConvPlan pl;
     if (!make_plan(d, &pl)) return DDNM_E_SHAPE;
+    if (d->skip0) {
+        if (!pl.halo || d->ups || !d->skip_weight || d->SC0 <= 0 || d->SC0 % KC || d->SC1 % KC ||
+            (d->SC1 > 0 && !d->skip1))
+            return DDNM_E_SHAPE;
+    }
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
         if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;      // no scratch: run unsplit

@@ -211,6 +211,9 @@ class Model:
             if rb.cin != rb.cout:
                 w[f"{n}.nin_shortcut.weight"] = ops.pack_conv_weight(g(f"{n}.nin_shortcut.weight"))
                 w[f"{n}.nin_shortcut.bias"] = g(f"{n}.nin_shortcut.bias")
+                # fused form: the 1x1 shortcut rides along conv2 as extra K chunks, biases summed
+                w[f"{n}.nin_shortcut.fused"] = ops.pack_skip_weight(g(f"{n}.nin_shortcut.weight"))
+                w[f"{n}.conv2_plus_shortcut.bias"] = (g(f"{n}.conv2.bias") + g(f"{n}.nin_shortcut.bias")).contiguous()
         w["temb_proj_cat.weight"] = torch.cat(tw, 0).contiguous()
         w["temb_proj_cat.bias"] = torch.cat(tb, 0).contiguous()
         attns = [a for (_, at, _, _) in self.down for a in at] + [self.mid[1]] + \
@@ -266,6 +269,11 @@ class Model:
                        badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total, emit_stats=True)
         gn2 = self._gn(h, None, n + ".norm2")
         if rb.cin != rb.cout:
+            B, H, W, _ = h.t.shape
+            if ops.conv_fuses_skip(B, H, W, rb.cout, rb.cout):
+                return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True,
+                                  bias=w[n + ".conv2_plus_shortcut.bias"], skip=(x0, x1),
+                                  skip_weight=w[n + ".nin_shortcut.fused"], emit_stats=True)
             xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"])
         else:
             assert x1 is None

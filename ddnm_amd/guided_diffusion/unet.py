@@ -226,8 +226,12 @@ class UNetModel:
                     fw.append(g(n + ".emb_layers.1.weight"))
                     fb.append(g(n + ".emb_layers.1.bias"))
                     if L[1] != L[2]:
-                        w[n + ".skip_connection.weight"] = ops.pack_conv_weight(g(n + ".skip_connection.weight"))
+                        raw = g(n + ".skip_connection.weight")
+                        w[n + ".skip_connection.weight"] = ops.pack_conv_weight(raw)
                         w[n + ".skip_connection.bias"] = g(n + ".skip_connection.bias")
+                        w[n + ".skip_connection.fused"] = ops.pack_skip_weight(raw)
+                        w[n + ".skip_connection.fused.f16"] = ops.pack_skip_weight(raw, f16=True)
+                        w[n + ".out_plus_skip.bias"] = (g(n + ".out_layers.3.bias") + g(n + ".skip_connection.bias")).contiguous()
                 else:
                     w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
                     w[n + ".qkv.weight"] = ops.pack_conv_weight(g(n + ".qkv.weight").unsqueeze(-1))
@@ -288,6 +292,14 @@ class UNetModel:
                            weight_f16=self._w16(n + ".in_layers.2.weight"))
             res_ups = False
             if cin != cout:
+                B, H, W, _ = h.t.shape
+                if ops.conv_fuses_skip(B, H, W, cout, cout):       # shortcut fused into out_layers.3 as extra K
+                    gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
+                    return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
+                                      bias=w[n + ".out_plus_skip.bias"], skip=(x0, x1),
+                                      skip_weight=w[n + ".skip_connection.fused"],
+                                      skip_weight_f16=w[n + ".skip_connection.fused.f16"], emit_stats=True,
+                                      weight_f16=self._w16(n + ".out_layers.3.weight"))
                 xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
                                 bias=w[n + ".skip_connection.bias"])
             else:

@@ -94,6 +94,20 @@ class Act:
         self.t, self.stats, self.tiles = t, stats, tiles
 
 
+def conv_fuses_skip(B, H, W, cin, cout):
+    """True when a 3x3 / stride-1 conv of this shape runs on the halo kernel, i.e. can take a fused shortcut."""
+    d = ConvDesc()
+    d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, H, W, cin, 0, cout
+    d.ksize, d.stride, d.pad, d.Ho, d.Wo = 3, 1, 1, H, W
+    return _lib.lib().ddnm_conv2d_f32_fuses_skip(ctypes.byref(d)) == 1
+
+
+def pack_skip_weight(w, f16=False):
+    """1x1 shortcut weights [Cout, Cin, 1, 1] -> [Cout_pad][Cin] (fp32, or fp16 for the fp16-operand kernel)."""
+    p = pack_conv_weight(w).reshape(-1, w.shape[1]).contiguous()
+    return p.to(torch.float16) if f16 else p
+
+
 def pack_conv_weight_f16(w):
     """OIHW fp32/fp16 -> (O, ky, kx, I) IEEE fp16, Cout padded to 128 (operands of ddnm_conv3x3_f16_f32)."""
     return pack_conv_weight(w).to(torch.float16).contiguous()
@@ -101,7 +115,7 @@ def pack_conv_weight_f16(w):
 
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
-           emit_stats=False, weight_f16=None):
+           emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
     With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them)."""
     src0 = src0.t if isinstance(src0, Act) else src0
@@ -134,6 +148,15 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     f16 = weight_f16 is not None and L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
     if f16:
         d.weight = weight_f16.data_ptr()
+    if skip is not None:
+        # fused 1x1 shortcut; the caller has checked `conv_fuses_skip` (3x3 halo launch)
+        s0 = skip[0].t if isinstance(skip[0], Act) else skip[0]
+        s1 = None if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1])
+        d.skip0, d.skip1 = _p(s0), _p(s1)
+        d.SC0, d.SC1 = s0.shape[3], (0 if s1 is None else s1.shape[3])
+        d.skip_weight = _p(skip_weight_f16) if f16 else _p(skip_weight)
+        if f16 and skip_weight_f16 is None:
+            raise ValueError("fp16 launch with a fused shortcut needs skip_weight_f16")
     fn_run = L.ddnm_conv3x3_f16_f32 if f16 else L.ddnm_conv2d_f32
     fn_tiles = L.ddnm_conv3x3_f16_stats_tiles if f16 else L.ddnm_conv2d_f32_stats_tiles
     fn_ws = L.ddnm_conv3x3_f16_workspace_floats if f16 else L.ddnm_conv2d_f32_workspace_floats

@@ -76,6 +76,12 @@ typedef struct ddnm_conv_desc {
     float* stats_out;       /* optional [B*tiles][Cout][2]: per-(M tile, channel) sum / sum of squares of `out`,
                                tiles = ddnm_conv2d_f32_stats_tiles(d) per image; feeds ddnm_gn_finalize_tiles_f32 so
                                the consumer's GroupNorm never re-reads the tensor */
+    /* fused 1x1 shortcut of a residual block (models.py:109,128-132; unet.py:222,256), 3x3 halo launches only:
+     * out += W_skip . concat_c(skip0, skip1) evaluated on the RAW tensors at the output pixel */
+    const float* skip0;     /* NHWC [B][Ho][Wo][SC0] or NULL */
+    const float* skip1;     /* NHWC [B][Ho][Wo][SC1] or NULL */
+    const float* skip_weight; /* packed [Cout_pad][SC0+SC1] (fp16 for ddnm_conv3x3_f16_f32) */
+    int32_t SC0, SC1;
 } ddnm_conv_desc;
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
@@ -86,6 +92,8 @@ int ddnm_conv2d_f32_tile_n(const ddnm_conv_desc* d);
 int64_t ddnm_conv2d_f32_workspace_floats(const ddnm_conv_desc* d);
 /* M tiles per image of the auto plan if this launch can emit `stats_out` (0: split-K or NCHW launch). */
 int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d);
+/* 1 if this launch would run the 3x3 halo kernel and can therefore take the fused shortcut fields. */
+int ddnm_conv2d_f32_fuses_skip(const ddnm_conv_desc* d);
 
 /* 3x3 / stride 1 / pad 1 convolution with fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate:
  * the reference's `use_fp16` torso (guided_diffusion/unet.py:619-625, fp16_util.py:15-22).  Same descriptor;

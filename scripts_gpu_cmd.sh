@@ -1,3 +1,4 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_gpu_cli.py -m gpu -q -k "class_conditional" 2>&1 | tail -5
-python bench.py --workload c5 --steps 1 --warmup 0 2>&1 | tail -1 | tee gpurun_out/bench_c5.json
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_adm.py -m gpu -q 2>&1 | tail -6
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c2', d['value'], d['ms_per_step'])"
+python tools/adm_probe.py 4 2>&1 | grep -E "^fp|halo_f16|gather"

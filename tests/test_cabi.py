@@ -45,8 +45,8 @@ def test_version_and_error_strings(lib):
 
 def test_struct_layouts_match_header():
     from ddnm_amd._lib import ConvDesc, GemmDesc, StepScalars
-    # 9 pointers + 16 int32 + pointer + int64 + 2 int32 + pointer (8-byte aligned)
-    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8 + 8 + 8
+    # 9 pointers + 16 int32 + pointer + int64 + 2 int32 + pointer + 3 pointers + 2 int32 (8-byte aligned)
+    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 3 * 8 + 8
     assert ConvDesc.workspace.offset == 9 * 8 + 16 * 4
     assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4 + 2 * 4
     assert ctypes.sizeof(StepScalars) == 24

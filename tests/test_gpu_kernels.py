@@ -292,3 +292,27 @@ def test_groupnorm_from_conv_epilogue_stats(hip, B, C0, C1, H):
     sc, sh = sc[:B * C].reshape(B, C).cpu(), sh[:B * C].reshape(B, C).cpu()
     got = xin * sc[:, :, None, None] + sh[:, :, None, None]
     assert rel(got, ref) < 3e-6
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_conv_fused_shortcut(hip, f16):
+    """conv2(3x3, GN+swish prologue) + 1x1 shortcut over the concat of two raw tensors, one launch."""
+    from ddnm_amd import ops
+    B, C, C0, C1, H = 4, 128, 128, 128, 32
+    if f16:
+        B, H = 4, 32                       # 4*1024/256 tiles
+    h = gen(B, C, H, H, seed=60)
+    a, b2 = gen(B, C0, H, H, seed=61), gen(B, C1, H, H, seed=62)
+    w2 = gen(C, C, 3, 3, seed=63, scale=(9 * C) ** -0.5)
+    ws = gen(C, C0 + C1, 1, 1, seed=64, scale=(C0 + C1) ** -0.5)
+    bias = gen(C, seed=65)
+    sc, sh = gen(B, C, seed=66), gen(B, C, seed=67)
+    act = h * sc[:, :, None, None] + sh[:, :, None, None]
+    act = act * torch.sigmoid(act)
+    ref = F.conv2d(act, w2, bias, padding=1) + F.conv2d(torch.cat([a, b2], 1), ws)
+    out = ops.conv2d(nhwc(h).cuda(), ops.pack_conv_weight(w2.cuda()), C, 3, gn=(sc.cuda().contiguous(), sh.cuda().contiguous()),
+                     bias=bias.cuda(), skip=(nhwc(a).cuda(), nhwc(b2).cuda()), skip_weight=ops.pack_skip_weight(ws.cuda()),
+                     skip_weight_f16=ops.pack_skip_weight(ws.cuda(), f16=True) if f16 else None,
+                     weight_f16=ops.pack_conv_weight_f16(w2.cuda()) if f16 else None)
+    torch.cuda.synchronize()
+    assert rel(nchw(out.cpu()), ref) < (2e-3 if f16 else 3e-6)
