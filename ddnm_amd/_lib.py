@@ -25,7 +25,7 @@ class ConvDesc(Structure):
         ("ups", c_int32), ("gn_silu", c_int32), ("out_nchw", c_int32),
         ("badd_stride", c_int32), ("tile", c_int32),
         ("workspace", c_void_p), ("workspace_floats", c_int64),
-        ("res_ups", c_int32), ("reserved", c_int32),
+        ("res_ups", c_int32), ("src_f16", c_int32),
         ("stats_out", c_void_p),
         ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
         ("SC0", c_int32), ("SC1", c_int32),
@@ -59,6 +59,8 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_fuses_skip": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_gn_apply_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_void_p]),
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                              c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
                                              c_void_p, c_void_p]),

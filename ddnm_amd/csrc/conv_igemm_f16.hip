@@ -22,17 +22,22 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 constexpr int KC16 = 64;            // channels per chunk
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 
-template <int WM, int WN, int MT, int NT>
+// SRC16 = the activation operand is already fp16 in HBM (written by ddnm_gn_apply_f16: GroupNorm affine +
+// swish applied ONCE per element instead of once per (output-channel tile x halo overlap) inside this kernel,
+// where the v_exp/v_rcp work of a 1024-output-channel layer is repeated 10x and costs 25 % of the kernel).
+template <int WM, int WN, int MT, int NT, bool SRC16>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int MAXH = BM == 256 ? 340 : (BM == 128 ? 204 : 136);
-    constexpr int HROWS_PER_PASS = NTHREADS / 16;                 // 16 float4 per 64-channel halo row
+    constexpr int HVEC = SRC16 ? 8 : 4;                           // channels per 16-byte global load
+    constexpr int HCOLS = KC16 / HVEC;                            // loads per 64-channel halo row
+    constexpr int HROWS_PER_PASS = NTHREADS / HCOLS;
     constexpr int HR = (MAXH + HROWS_PER_PASS - 1) / HROWS_PER_PASS;
     constexpr int BROWS_PER_PASS = NTHREADS / 8;                  // 8 x 16 B per 64-half weight row
     constexpr int BR = BN / BROWS_PER_PASS;
     static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
-    __shared__ __attribute__((aligned(16))) _Float16 Hs[MAXH * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 Hs[2 * MAXH * LDH];      // halo double-buffered (see main loop)
     __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BN * LDH];
     __shared__ __attribute__((aligned(16))) float stat_lds[WM * BN * 2];
 
@@ -47,8 +52,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const int TH = BM >> p.TW_log2, HWd = p.TW + 2;
     const int NP = (TH + 2) * HWd;
 
-    // ---- halo loader mapping: thread -> (float4 column c4 of 16, halo rows prow + HROWS_PER_PASS*i)
-    const int c4 = tid & 15, prow = tid >> 4;
+    // ---- halo loader mapping: thread -> (16-byte column hc of HCOLS, halo rows prow + HROWS_PER_PASS*i)
+    const int hc = tid % HCOLS, prow = tid / HCOLS;
     int hoff[HR];
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
@@ -66,43 +71,55 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const int nchunks = p.Cin / KC16;
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
 
-    f32x4 h_st[HR];
+    uint4 h_st[HR];                                 // fp32 mode: 4 floats (bit-cast); fp16 mode: 8 halfs
     uint4 b_st[BR];
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
-    const bool has_gn = d.gn_scale != nullptr;
+    const bool has_gn = !SRC16 && d.gn_scale != nullptr;
 
-    auto prefetch_halo = [&](int chunk) {
+    constexpr int HSPLIT = (HR + 1) / 2;            // row slots [0, HSPLIT) and [HSPLIT, HR) are loaded / staged separately
+    auto prefetch_halo_part = [&](int chunk, int i0, int i1) {
         const int cb = chunk * KC16;
-        const float* src;
+        const char* src;
         int cs, coff;
-        if (cb < d.C0) { src = d.src0; cs = d.C0; coff = cb; }
-        else { src = d.src1; cs = d.C1; coff = cb - d.C0; }
+        if (cb < d.C0) { src = reinterpret_cast<const char*>(d.src0); cs = d.C0; coff = cb; }
+        else { src = reinterpret_cast<const char*>(d.src1); cs = d.C1; coff = cb - d.C0; }
+        constexpr int ESZ = SRC16 ? 2 : 4;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
+            if (i < i0 || i >= i1) continue;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (hoff[i] >= 0) v = *reinterpret_cast<const uint4*>(src + ((size_t)hoff[i] * cs + coff + hc * HVEC) * ESZ);
             h_st[i] = v;
         }
-        if (has_gn) {
-            gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + c4 * 4);
-            gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + c4 * 4);
+        if constexpr (!SRC16) {
+            if (has_gn && i0 == 0) {
+                gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + hc * 4);
+                gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + hc * 4);
+            }
         }
     };
+    auto prefetch_halo = [&](int chunk) { prefetch_halo_part(chunk, 0, HR); };
     auto prefetch_b = [&](int chunk, int tap) {
         const _Float16* wp = wbase + (size_t)tap * p.Cin + chunk * KC16;
 #pragma unroll
         for (int i = 0; i < BR; ++i)
             b_st[i] = *reinterpret_cast<const uint4*>(wp + (size_t)(BROWS_PER_PASS * i) * 9 * p.Cin);
     };
-    auto stage_halo = [&](bool apply_gn = true) {
+    auto stage_halo_part = [&](int hbuf, int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
+            if (i < i0 || i >= i1) continue;
             const int row = prow + HROWS_PER_PASS * i;
             if (row < MAXH) {
-                f32x4 v = h_st[i];
-                if (apply_gn && has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
-                half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                *reinterpret_cast<half4*>(&Hs[row * LDH + c4 * 4]) = h;
+                _Float16* dst = &Hs[hbuf * MAXH * LDH + row * LDH + hc * HVEC];
+                if constexpr (SRC16) {
+                    *reinterpret_cast<uint4*>(dst) = h_st[i];
+                } else {
+                    f32x4 v = __builtin_bit_cast(f32x4, h_st[i]);
+                    if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+                    half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    *reinterpret_cast<half4*>(dst) = h;
+                }
             }
         }
     };
@@ -129,9 +146,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     }
     const _Float16* b_frag = Bs + (wn * NT * 32) * LDH + (lane & 31) * LDH + (lane >> 5) * 8;
 
-    auto mfma_tap = [&](int tap, int buf) {
+    auto mfma_tap = [&](int tap, int buf, int hbuf = 0) {
         const int ky = tap / 3, kx = tap - 3 * ky;
-        const int tap_off = (ky * HWd + kx) * LDH;
+        const int tap_off = (ky * HWd + kx) * LDH + hbuf * MAXH * LDH;
         const _Float16* bf = b_frag + buf * BN * LDH;
 #pragma unroll
         for (int ks = 0; ks < KC16 / 16; ++ks) {
@@ -148,38 +165,63 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         }
     };
 
+    // Main loop.  Weight tile: double-buffered, loads two taps ahead (one barrier per tap).  Halo: double-buffered
+    // too -- the next chunk's halo is loaded in two halves (taps 0 and 3) and converted / GroupNorm'd / written
+    // to the OTHER halo buffer at taps 3 and 6, between MFMA batches, so a chunk boundary costs nothing
+    // (re-staging it between two barriers used to be 28 % of the kernel).
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         prefetch_b(c_begin, 0);
-        stage_halo();
+        stage_halo_part(0, 0, HR);
         stage_b(0);
         prefetch_b(c_begin, 1);
         __syncthreads();
-        int cur = 0;
+        int cur = 0, hb = 0;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const bool more = chunk + 1 < c_end;
             for (int tap = 0; tap < 9; ++tap) {
-                const bool last_tap = tap == 8, more = chunk + 1 < c_end;
+                const bool last_tap = tap == 8;
                 if (!last_tap || more) {
                     stage_b(cur ^ 1);
                     if (tap < 7) prefetch_b(chunk, tap + 2);
-                    else if (tap == 7) { if (more) { prefetch_b(chunk + 1, 0); prefetch_halo(chunk + 1); } }
+                    else if (tap == 7) { if (more) prefetch_b(chunk + 1, 0); }
                     else if (more) prefetch_b(chunk + 1, 1);
                 }
-                mfma_tap(tap, cur);
-                __syncthreads();
-                if (last_tap && more) {
-                    stage_halo();
-                    __syncthreads();
+                if (more) {
+                    if (tap == 0) prefetch_halo_part(chunk + 1, 0, HSPLIT);
+                    if (tap == 3) { stage_halo_part(hb ^ 1, 0, HSPLIT); prefetch_halo_part(chunk + 1, HSPLIT, HR); }
+                    if (tap == 6) stage_halo_part(hb ^ 1, HSPLIT, HR);
                 }
+                mfma_tap(tap, cur, hb);
+#ifndef DDNM_PROBE16_NO_TAP_BARRIER
+                __syncthreads();
+#endif
                 cur ^= 1;
             }
+            hb ^= 1;
         }
+        // the shortcut phase and the statistics epilogue below use halo buffer 0 / Bs buffer 0
     }
     // ---- fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's
     // raw input at the centre tap (see conv_igemm_f32.hip)
     if (d.skip0 != nullptr && slice == 0) {
         const int SCin = d.SC0 + d.SC1, nsk = SCin / KC16;
         const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin + c8 * 8;
+        // the raw input is fp32: thread -> (float4 column sc of 16, interior pixels srow + 32*i), staged at the
+        // pixel's halo position so that mfma_tap(4) (centre tap) reads it
+        constexpr int SR = BM * 16 / NTHREADS;
+        const int sc = tid & 15, srow = tid >> 4;
+        int soff[SR], sdst[SR];
+#pragma unroll
+        for (int i = 0; i < SR; ++i) {
+            const int m = srow + (NTHREADS / 16) * i;
+            const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
+            const int iy = tm.ty0 + ty, ix = tm.tx0 + tx;
+            const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+            soff[i] = (img * p.Hs + sy) * p.Ws + sx;
+            sdst[i] = ((ty + 1) * HWd + tx + 1) * LDH + sc * 4;
+        }
+        f32x4 s_st[SR];
         auto prefetch_skip = [&](int ch) {
             const int cb = ch * KC16;
             const float* src;
@@ -187,11 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             if (cb < d.SC0) { src = d.skip0; cs = d.SC0; coff = cb; }
             else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
 #pragma unroll
-            for (int i = 0; i < HR; ++i) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (hoff[i] >= 0) v = *reinterpret_cast<const f32x4*>(src + (size_t)hoff[i] * cs + coff + c4 * 4);
-                h_st[i] = v;
-            }
+            for (int i = 0; i < SR; ++i) s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)soff[i] * cs + coff + sc * 4);
 #pragma unroll
             for (int i = 0; i < BR; ++i)
                 b_st[i] = *reinterpret_cast<const uint4*>(swbase + (size_t)(BROWS_PER_PASS * i) * SCin + cb);
@@ -199,7 +237,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         prefetch_skip(0);
         for (int ch = 0; ch < nsk; ++ch) {
             __syncthreads();
-            stage_halo(false);
+#pragma unroll
+            for (int i = 0; i < SR; ++i) {
+                const f32x4 v = s_st[i];
+                half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                *reinterpret_cast<half4*>(&Hs[sdst[i]]) = h;
+            }
             stage_b(0);
             __syncthreads();
             if (ch + 1 < nsk) prefetch_skip(ch + 1);
@@ -261,6 +304,7 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
+    if (d->src_f16 && d->gn_scale) return DDNM_E_BADARG;
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     PlanF16 pl;
@@ -288,7 +332,11 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     p.ksplit = pl.ksplit;
     p.ws = d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
+    if (d->src_f16) {
+        DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
+    } else {
+        DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
+    }
     if (pl.ksplit > 1) {
         const size_t total4 = (size_t)d->B * d->Ho * d->Wo * d->Cout / 4;
         const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);

@@ -5,7 +5,7 @@
 // convolution applies while it stages its A tile (conv_igemm_f32.hip).
 // Replaces torch.nn.GroupNorm(32, C, eps) -- guided_diffusion/models.py:32-33,
 // guided_diffusion/nn.py:17-19,93-100.
-#include "common.h"
+#include "conv_common.h"
 
 constexpr int GN_PIX_PER_THREAD = 64;
 
@@ -212,5 +212,45 @@ extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int3
     if (groups <= 0 || C % groups) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_tiles_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, part0, tpi0, C0, part1, tpi1,
                 C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride, mean_rstd);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm affine + swish applied once, written as fp16 (operand of conv3x3_halo_f16_kernel<SRC16>).
+// HBM-bound: 4 B read + 2 B written per element; thread = 8 consecutive channels of one pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_f16_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           _Float16* __restrict__ out, int HW, int C0, int C1, int silu,
+                                                           size_t total8) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int C = C0 + C1, C8 = C >> 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / C8;
+        const int c = (int)(i - pix * C8) * 8;
+        const int b = (int)(pix / HW);
+        const float* s = c < C0 ? src0 + pix * C0 + c : src1 + pix * C1 + (c - C0);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(s), v1 = *reinterpret_cast<const f32x4*>(s + 4);
+        const float* sc = scale + (size_t)b * C + c;
+        const float* sh = shift + (size_t)b * C + c;
+        const f32x4 r0 = gn_act(v0, *reinterpret_cast<const f32x4*>(sc), *reinterpret_cast<const f32x4*>(sh), silu);
+        const f32x4 r1 = gn_act(v1, *reinterpret_cast<const f32x4*>(sc + 4), *reinterpret_cast<const f32x4*>(sh + 4), silu);
+        half8 h = {(_Float16)r0.x, (_Float16)r0.y, (_Float16)r0.z, (_Float16)r0.w,
+                   (_Float16)r1.x, (_Float16)r1.y, (_Float16)r1.z, (_Float16)r1.w};
+        *reinterpret_cast<half8*>(out + i * 8) = h;
+    }
+}
+
+extern "C" int ddnm_gn_apply_f16(const float* src0, const float* src1, const float* scale, const float* shift, void* out_f16,
+                                 int32_t B, int32_t HW, int32_t C0, int32_t C1, int32_t silu, void* stream) {
+    if (!src0 || !scale || !shift || !out_f16 || B <= 0 || HW <= 0 || C0 <= 0 || C1 < 0) return DDNM_E_BADARG;
+    if ((C0 | C1) & 7) return DDNM_E_SHAPE;
+    if (C1 > 0 && !src1) return DDNM_E_BADARG;
+    const size_t total8 = (size_t)B * HW * (C0 + C1) / 8;
+    const size_t blocks = (total8 + 255) / 256;
+    const unsigned g = (unsigned)(blocks < 16384 ? blocks : 16384);
+    DDNM_LAUNCH(gn_apply_f16_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src0, src1, scale, shift,
+                reinterpret_cast<_Float16*>(out_f16), HW, C0, C1, silu, total8);
     return 0;
 }

@@ -113,6 +113,19 @@ def pack_conv_weight_f16(w):
     return pack_conv_weight(w).to(torch.float16).contiguous()
 
 
+_F16_PREPASS_MIN_COUT = int(_os.environ.get("DDNM_F16_PREPASS_MIN_COUT", "256"))
+_f16_scratch_buf = {}
+
+
+def _f16_scratch(device, numel):
+    """fp16 activation scratch of the GroupNorm pre-pass (stream order makes reuse safe)."""
+    buf = _f16_scratch_buf.get(device)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(numel, dtype=torch.float16, device=device)
+        _f16_scratch_buf[device] = buf
+    return buf
+
+
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
            emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None):
@@ -148,6 +161,14 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     f16 = weight_f16 is not None and L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
     if f16:
         d.weight = weight_f16.data_ptr()
+        if gn is not None and cout >= _F16_PREPASS_MIN_COUT:
+            # GroupNorm + swish once per element into an fp16 scratch tensor instead of once per
+            # (128-output-channel tile x halo overlap) inside the conv's loader
+            h16 = _f16_scratch(src0.device, B * Hs * Ws * (C0 + C1))
+            check(L.ddnm_gn_apply_f16(_p(src0), _p(src1), _p(gn[0]), _p(gn[1]), h16.data_ptr(), B, Hs * Ws, C0, C1,
+                                      int(gn_silu), _stream()), "ddnm_gn_apply_f16")
+            d.src0, d.src1, d.C0, d.C1 = h16.data_ptr(), None, C0 + C1, 0
+            d.gn_scale, d.gn_shift, d.src_f16 = None, None, 1
     if skip is not None:
         # fused 1x1 shortcut; the caller has checked `conv_fuses_skip` (3x3 halo launch)
         s0 = skip[0].t if isinstance(skip[0], Act) else skip[0]

@@ -72,7 +72,8 @@ typedef struct ddnm_conv_desc {
     int64_t workspace_floats;
     int32_t res_ups;        /* 1: `res` is [B][Ho/2][Wo/2][Cout], added through a nearest x2 upsample
                                (x_upd of an `up=True` ResBlock, guided_diffusion/unet.py:237-242) */
-    int32_t reserved;
+    int32_t src_f16;        /* ddnm_conv3x3_f16_f32 only: src0/src1 point to IEEE fp16 NHWC tensors (the output of
+                               ddnm_gn_apply_f16); gn_scale must then be NULL */
     float* stats_out;       /* optional [B*tiles][Cout][2]: per-(M tile, channel) sum / sum of squares of `out`,
                                tiles = ddnm_conv2d_f32_stats_tiles(d) per image; feeds ddnm_gn_finalize_tiles_f32 so
                                the consumer's GroupNorm never re-reads the tensor */
@@ -124,6 +125,12 @@ int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gam
 
 /* GroupNorm affine from the partials a convolution epilogue emitted (`stats_out`); the input may be the
  * channel concat of two tensors (part1 / tpi1 / C1, or NULL / 0 / 0). */
+/* GroupNorm affine (+ swish) applied once and written as fp16 for ddnm_conv3x3_f16_f32(src_f16 = 1):
+ * out[b,p,c] = fp16(act(concat_c(src0, src1)[b,p,c] * scale[b,c] + shift[b,c])), identical rounding to the fused
+ * prologue.  C0 % 8 == 0, C1 % 8 == 0.  Layers with >= 256 output channels use this instead of the fused prologue,
+ * which repeats the v_exp / v_rcp work once per 128-output-channel tile. */
+int ddnm_gn_apply_f16(const float* src0, const float* src1, const float* scale, const float* shift, void* out_f16,
+                      int32_t B, int32_t HW, int32_t C0, int32_t C1, int32_t silu, void* stream);
 int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tiles_per_img0, int32_t C0, const float* part1,
                                int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
                                int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,

@@ -131,6 +131,26 @@ def test_conv3x3_f16_operands(hip, B, C0, C1, Cout, H, gn, res, ups):
     assert rel(got, ref32) < 2e-3
 
 
+@pytest.mark.parametrize("C0,C1,Cout,H,ups", [(256, 0, 256, 32, False), (256, 256, 256, 32, False), (128, 0, 512, 16, True)])
+def test_conv3x3_f16_groupnorm_prepass_is_bit_identical(hip, monkeypatch, C0, C1, Cout, H, ups):
+    """ddnm_gn_apply_f16 + conv(src_f16) == the fused GroupNorm/swish prologue, bit for bit (same fp32 math,
+    same rounding point, same MFMA order)."""
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, Cin = 2, C0 + C1
+    a = torch.randn(B, H, H, C0, generator=g).cuda()
+    b = torch.randn(B, H, H, C1, generator=g).cuda() if C1 else None
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).cuda()
+    sc, sh = torch.randn(B, Cin, generator=g).cuda(), torch.randn(B, Cin, generator=g).cuda()
+    w32, w16 = ops.pack_conv_weight(w), ops.pack_conv_weight_f16(w)
+    outs = []
+    for min_cout in (1 << 30, 0):
+        monkeypatch.setattr(ops, "_F16_PREPASS_MIN_COUT", min_cout)
+        outs.append(ops.conv2d(a, w32, Cout, 3, src1=b, gn=(sc, sh), gn_silu=True, ups=ups, weight_f16=w16).clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("kind,batch", [("mid", 2), ("full", 1)])
 def test_adm_forward_fp16_torso(hip, kind, batch, golden_dir):
     """`convert_to_fp16()` engine vs the fp32 goldens of the reference: single-forward rel-L2 <= 3e-3
