@@ -59,6 +59,7 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_fuses_skip": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_patchify_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_gn_apply_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,

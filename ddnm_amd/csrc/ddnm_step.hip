@@ -555,3 +555,33 @@ extern "C" int ddnm_axpby_strided_f32(const float* x, int64_t x_bstride, const f
                 total, a, b);
     return 0;
 }
+
+
+// Block-based CS (svd_operators.py:101-159): ps x ps patches of every plane as rows of a [patches][ps*ps] matrix
+// (unfold(2,ps,ps).unfold(3,ps,ps), :134-135) so that Vt_small / V_small act as ONE MFMA GEMM over all patches.
+// float4 along the patch row (ps % 4 == 0): both sides move 16-byte pieces; HBM-bound, 8 B per element.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ src, float* __restrict__ dst, int D,
+                                                       int ps, int inverse, int64_t total4) {
+    const int ps4 = ps >> 2, npd = D / ps;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        // i indexes the patch-matrix side: (((plane*npd + py)*npd + px)*ps + r)*ps4 + q
+        int64_t t = i;
+        const int q = (int)(t % ps4); t /= ps4;
+        const int r = (int)(t % ps); t /= ps;
+        const int px = (int)(t % npd); t /= npd;
+        const int py = (int)(t % npd);
+        const int64_t plane = t / npd;
+        const int64_t img = ((plane * D + py * ps + r) * D + px * ps) / 4 + q;
+        if (inverse) reinterpret_cast<f32x4*>(dst)[img] = reinterpret_cast<const f32x4*>(src)[i];
+        else reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[img];
+    }
+}
+
+extern "C" int ddnm_patchify_f32(const float* src, float* dst, int32_t planes, int32_t D, int32_t ps, int32_t inverse,
+                                 void* stream) {
+    if (!src || !dst || planes <= 0 || D <= 0 || ps <= 0) return DDNM_E_BADARG;
+    if (D % ps || ps % 4) return DDNM_E_SHAPE;
+    const int64_t total4 = (int64_t)planes * D * D / 4;
+    DDNM_LAUNCH(patchify_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, src, dst, D, ps, inverse, total4);
+    return 0;
+}

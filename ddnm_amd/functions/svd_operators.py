@@ -404,6 +404,98 @@ class WalshHadamardCS(A_functions):
         ops.step_combine(x0_out, proj, self._apy, noise, et, s, out=xt_next)
 
 
+class CS(A_functions):
+    """Block-based compressed sensing, svd_operators.py:101-159: every 32x32 patch of every channel is measured by
+    the first `32*32*ratio` rows of Vt_small, the right-singular basis of one Gaussian 1024x1024 matrix (:107-108);
+    all singular values are 1 (:110), so A^+ = A^T.  Here: one patch-gather pass + ONE MFMA GEMM over all
+    B*C*(D/32)^2 patches per A / A^+ (the reference runs 1024x1024 mat-vecs through torch.matmul broadcasting and
+    then re-sorts the coefficient vector, :113-146).  `gauss`: the Gaussian matrix (default: torch.randn from the
+    global CPU generator exactly like :107); the SVD runs on the host like every other operator constructor."""
+
+    PATCH = 32
+
+    def __init__(self, channels, img_dim, ratio, device, gauss=None):
+        ps = self.PATCH
+        if img_dim % ps:
+            raise ValueError("img_dim must be a multiple of 32")
+        self.channels, self.img_dim, self.device = channels, img_dim, device
+        self.y_dim, self.ratio = img_dim // ps, ps
+        if gauss is None:
+            gauss = torch.randn(ps ** 2, ps ** 2)
+        _, _, V = torch.svd(gauss.detach().float().cpu(), some=False)
+        self.cs_size = int(ps * ps * ratio)
+        self.V_small = V.contiguous().to(device)
+        self.M = V[:, :self.cs_size].T.contiguous().to(device)             # [cs, 1024] = Vt_small[:cs]
+
+    def _npatch(self, B):
+        return B * self.channels * self.y_dim ** 2
+
+    def A(self, vec):
+        x = _img(vec, self.channels, self.img_dim)
+        B, ps2, cs = x.shape[0], self.ratio ** 2, self.cs_size
+        npatch = self._npatch(B)
+        P = torch.empty(npatch, ps2, dtype=torch.float32, device=x.device)
+        check(_lib.lib().ddnm_patchify_f32(_p(x), _p(P), B * self.channels, self.img_dim, self.ratio, 0, ops._stream()),
+              "ddnm_patchify_f32")
+        y = torch.empty(B, self.channels * self.y_dim ** 2 * cs, dtype=torch.float32, device=x.device)
+        ops.bgemm(P, self.M, y, npatch, cs, ps2, lda=ps2, ldb=ps2, ldc=cs, transb=True)      # (c, patch, k) order, :143
+        return y
+
+    def A_pinv(self, vec):
+        B, ps2, cs = vec.shape[0], self.ratio ** 2, self.cs_size
+        y = vec.reshape(B, -1).float().contiguous()
+        npatch = self._npatch(B)
+        P = torch.empty(npatch, ps2, dtype=torch.float32, device=y.device)
+        ops.bgemm(y, self.M, P, npatch, ps2, cs, lda=cs, ldb=ps2, ldc=ps2, transb=False)
+        x = torch.empty(B, self.channels * self.img_dim ** 2, dtype=torch.float32, device=y.device)
+        check(_lib.lib().ddnm_patchify_f32(_p(P), _p(x), B * self.channels, self.img_dim, self.ratio, 1, ops._stream()),
+              "ddnm_patchify_f32")
+        return x
+
+    def singulars(self):
+        return torch.ones(self.cs_size, device=self.device).repeat(self.channels * self.y_dim ** 2)
+
+
+class PixelMask(A_functions):
+    """A = A^+ = z * mask of the simplified path (guided_diffusion/diffusion.py:258-259,263-264)."""
+
+    def __init__(self, channels, img_dim, mask, device):
+        self.channels, self.img_dim, self.device = channels, img_dim, device
+        self.mask = mask.reshape(-1).float().to(device).contiguous()       # [HW], shared by the channel planes
+
+    def A(self, vec):
+        return _mask_mix(_flat(vec), None, self.mask, 1, self.img_dim ** 2, 1.0, 0.0)
+
+    A_pinv = A
+
+
+class Composition(A_functions):
+    """A = A_n ... A_2 A_1 and the reference's "pseudo-inverse" A_1^+ A_2^+ ... A_n^+ of the simplified path's
+    composed degradations (mask_color_sr / diy, guided_diffusion/diffusion.py:260-290)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self.channels, self.img_dim, self.device = parts[0].channels, parts[0].img_dim, parts[0].device
+
+    def A(self, vec):
+        for op in self.parts:
+            vec = op.A(vec)
+        return vec
+
+    def A_pinv(self, vec):
+        for op in reversed(self.parts):
+            vec = op.A_pinv(vec)
+        return vec
+
+
+def mask_color_sr(channels, img_dim, mask, scale, device):
+    """`--deg mask_color_sr` / `diy` (diffusion.py:260-290): mask, then grey (color2gray :33-36), then average-pool.
+    The reference keeps three identical grey channels; one is kept here (same information, same A^+ A)."""
+    return Composition([PixelMask(channels, img_dim, mask, device),
+                        Colorization(img_dim, device, weights=(1 / 3, 1 / 3, 1 / 3)),
+                        SuperResolution(1, img_dim, int(scale), device)])
+
+
 class SRConv(A_functions):
     ZERO = 3e-2     # svd_operators.py:878
 
@@ -574,8 +666,7 @@ def build_operator(deg, deg_scale, config, device, mask_path="exp/inp_masks/mask
         k2, k1 = gaussian_taps(20, 4), gaussian_taps(1, 4)
         return Deblurring2D(k1 / k1.sum(), k2 / k2.sum(), c, d, device)
     if deg == "cs_blockbased":
-        raise NotImplementedError("block-based CS draws its sensing matrix from the device RNG (svd_operators.py:107); "
-                                  "listed under 'next' (SURVEY.md section 8f rank 2)")
+        return CS(c, d, deg_scale, device)                   # diffusion.py:459-462
     raise ValueError("degradation type not supported")
 
 

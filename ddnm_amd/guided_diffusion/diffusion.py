@@ -23,7 +23,8 @@ import torch.utils.data as data
 from .. import dist as ddist
 from .. import ops
 from ..functions.svd_ddnm import _AlphaTable, ddnm_diffusion, ddnm_plus_diffusion, get_schedule_jump
-from ..functions.svd_operators import (Colorization, Denoising, Inpainting, SuperResolution, build_operator)
+from ..functions.svd_operators import (Colorization, Denoising, Inpainting, SuperResolution, build_operator,
+                                      mask_color_sr)
 from .models import Model
 
 
@@ -337,8 +338,9 @@ class Diffusion(object):
             mask = torch.from_numpy(np.load("exp/inp_masks/mask.npy")).reshape(-1)      # A = Ap = z * mask
             r = torch.nonzero(mask == 0).long().reshape(-1) * 3
             return Inpainting(config.data.channels, d, torch.cat([r, r + 1, r + 2], 0), dev)
-        if args.deg in ("mask_color_sr", "diy"):
-            raise NotImplementedError("composed degradations are listed under 'next' (SURVEY.md section 8f rank 2)")
+        if args.deg in ("mask_color_sr", "diy"):                                         # :260-290
+            mask = torch.from_numpy(np.load("exp/inp_masks/mask.npy"))
+            return mask_color_sr(config.data.channels, d, mask, round(args.deg_scale), dev)
         raise NotImplementedError("degradation type not supported")
 
     def simplified_ddnm_plus(self, model, cls_fn):

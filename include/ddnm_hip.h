@@ -295,6 +295,11 @@ int ddnm_wh_gather_f32(const float* planes, const int32_t* perm, float* y, int32
 int ddnm_wh_scatter_f32(const float* y, const int32_t* perm, float* planes, int32_t B, int32_t C, int32_t N,
                         int32_t n_keep, void* stream);
 
+/* Block-based CS, svd_operators.py:101-159: every ps x ps patch of every plane [planes][D][D] becomes one row of
+ * patches[planes*(D/ps)^2][ps*ps] (row = plane, py, px; column = i*ps + j), inverse = 1 scatters the rows back.
+ * Vt_small / V_small (:108-109) then act as one ddnm_bgemm_f32 over all patches.  D % ps == 0, ps % 4 == 0. */
+int ddnm_patchify_f32(const float* src, float* dst, int32_t planes, int32_t D, int32_t ps, int32_t inverse, void* stream);
+
 /* inverse_data_transform + per-image MSE (datasets/__init__.py:218-227; diffusion.py:599-602):
  * img = clamp((x+1)/2, 0, 1); mse[b] = mean((img - clamp((x_orig+1)/2,0,1))^2) */
 int ddnm_finalize_psnr_f32(const float* x, const float* x_orig, float* img /* may be NULL */, double* sse /* [B], zeroed by callee */,

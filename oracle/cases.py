@@ -70,6 +70,8 @@ def make_operator(name, img_dim, mask=None):
     if name == "deblur_aniso":
         k2, k1 = O.gaussian_taps(20, 4), O.gaussian_taps(1, 4)
         return O.Deblurring2D(k1 / k1.sum(), k2 / k2.sum(), 3, img_dim)
+    if name == "cs_blockbased":
+        return O.CS(3, img_dim, 0.25, O.gauss_matrix(SEED + 21))
     raise ValueError(name)
 
 

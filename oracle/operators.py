@@ -428,3 +428,60 @@ class Deblurring(Deblurring2D):
 def gaussian_taps(sigma, radius):
     """diffusion.py:507-520: exp(-0.5 (x/sigma)^2) evaluated in fp32, x = -radius..radius."""
     return torch.tensor([float(torch.exp(torch.Tensor([-0.5 * (x / sigma) ** 2]))) for x in range(-radius, radius + 1)])
+
+
+# =================================================================================================
+# Block-based compressed sensing (functions/svd_operators.py:101-159)
+# =================================================================================================
+def gauss_matrix(seed):
+    """The 1024x1024 Gaussian matrix of svd_operators.py:107 as drawn after torch.manual_seed(seed)."""
+    return torch.randn(32 ** 2, 32 ** 2, generator=torch.Generator().manual_seed(seed))
+
+
+class CS:
+    """Every 32x32 patch p of every channel is expanded in the right-singular basis of one Gaussian matrix,
+    c = Vt_small p (:134-138); the spectral vector lists the first `cs` coefficients of all (channel, patch)
+    pairs, then the rest (:140-145).  All singular values are 1 (:110), so A keeps the first block and
+    A^+ = V(pad(.)) puts it back (:52-58,68-80)."""
+
+    def __init__(self, channels, img_dim, ratio, gauss):
+        self.channels, self.img_dim, self.n = channels, img_dim, img_dim // 32
+        _, _, V = torch.svd(gauss.float(), some=False)                       # :108
+        self.cs = int(32 * 32 * ratio)                                       # :110-111
+        self.Vt_cs = V.T[:self.cs].contiguous()
+
+    def A(self, x):
+        b, c, n = x.shape[0], self.channels, self.n
+        patches = x.reshape(b, c, n, 32, n, 32).permute(0, 1, 2, 4, 3, 5).reshape(b, c, n * n, 1024)
+        return (patches @ self.Vt_cs.T).reshape(b, -1)
+
+    def A_pinv(self, y):
+        b, c, n = y.shape[0], self.channels, self.n
+        patches = y.reshape(b, c, n * n, self.cs) @ self.Vt_cs
+        return patches.reshape(b, c, n, n, 32, 32).permute(0, 1, 2, 4, 3, 5).reshape(b, -1)
+
+
+# =================================================================================================
+# Composed degradation of the simplified path (guided_diffusion/diffusion.py:260-290)
+# =================================================================================================
+def color2gray(x):
+    """guided_diffusion/diffusion.py:33-36."""
+    g = x[:, 0] * (1 / 3) + x[:, 1] * (1 / 3) + x[:, 2] * (1 / 3)
+    return g[:, None].repeat(1, 3, 1, 1)
+
+
+def gray2color(x):
+    """guided_diffusion/diffusion.py:38-42."""
+    coef = 1 / 3
+    base = 3 * coef ** 2
+    return torch.stack([x[:, 0] * coef / base] * 3, 1)
+
+
+def mask_color_sr(mask, scale, img_dim):
+    """(A, Ap) of `--deg mask_color_sr` / `diy`: A = pool(gray(mask * z)), Ap = mask * color(upsample(z))."""
+    pool = torch.nn.AdaptiveAvgPool2d((img_dim // scale, img_dim // scale))
+
+    def up(z):
+        return z.repeat_interleave(scale, dim=2).repeat_interleave(scale, dim=3)      # MeanUpsample, :27-31
+
+    return (lambda z: pool(color2gray(z * mask))), (lambda z: gray2color(up(z)) * mask)

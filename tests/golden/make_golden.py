@@ -129,6 +129,35 @@ def make_deblur():
     np.savez_compressed(os.path.join(HERE, "deblur.npz"), **out)
 
 
+def make_cs():
+    """CS (block-based compressed sensing) of the reference at 64^2, ratio 0.25: A, A_pinv and one 12-step sampler
+    run on the small celeba net.  The constructor draws its Gaussian matrix from the global RNG (:107)."""
+    from oracle import operators as O
+    ns = ref_import.load()
+    R = ns.svd_operators
+    torch.manual_seed(cases.SEED + 21)
+    op = R.CS(3, 64, 0.25, "cpu")
+    _, _, V = torch.svd(O.gauss_matrix(cases.SEED + 21), some=False)
+    assert torch.equal(V, op.V_small), "oracle.gauss_matrix must reproduce the reference's draw"
+    x = cases.operator_input(64, 2)
+    y = op.A(x)
+    out = {"y": y.numpy(), "pinv": op.A_pinv(y.clone()).numpy(), "singulars_sum": np.array([op.singulars().sum().item()])}
+    cfg, sd = cases.celeba_net("small")
+    ref = ns.models.Model(cfg)
+    ref.load_state_dict(sd)
+    ref.eval()
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 12, 1, 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 2, 12)
+    torch.manual_seed(cases.SEED + 21)
+    op = R.CS(3, cfg.data.image_size, 0.25, "cpu")
+    yy = op.A(x_orig)
+    with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+        xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, yy, cls_fn=None, classes=None,
+                                             config=cfg)
+    out["sampler_x"], out["sampler_x0"] = xs[0].numpy(), x0s[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "cs_blockbased.npz"), **out)
+
+
 def make_plus():
     """ddnm_plus_diffusion (functions/svd_ddnm.py:80-164) of the reference: small celeba net, sigma_y = 0.2
     (doubled value, as the runner passes it), 20 steps with time travel, every operator that has Lambda."""
@@ -196,11 +225,14 @@ def main():
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
+    ap.add_argument("--cs-only", action="store_true", help="only (re)generate the block-based CS goldens")
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     args = ap.parse_args()
     if args.classifier_only:
         return make_classifier()
+    if args.cs_only:
+        return make_cs()
     if args.deblur_only:
         return make_deblur()
     if args.adm_only:

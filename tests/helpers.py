@@ -33,6 +33,9 @@ def engine_operator(name, d, mask=None, device="cuda"):
     if name in ("deblur_uni", "deblur_gauss", "deblur_aniso"):
         cfg = cases.weights.celeba_config(resolution=d)
         return E.build_operator(name, 0, cfg, device)
+    if name == "cs_blockbased":
+        from oracle import operators as O
+        return E.CS(3, d, 0.25, device, gauss=O.gauss_matrix(cases.SEED + 21))
     raise ValueError(name)
 
 

@@ -25,7 +25,8 @@ def _reduced_yaml(tmp_path, T=5, batch=2):
         yaml.safe_dump(cfg, f)
 
 
-@pytest.mark.parametrize("deg,scale", [("sr_bicubic", "4"), ("colorization", "0"), ("cs_walshhadamard", "0.25")])
+@pytest.mark.parametrize("deg,scale", [("sr_bicubic", "4"), ("colorization", "0"), ("cs_walshhadamard", "0.25"),
+                                       ("cs_blockbased", "0.25")])
 def test_main_cli_end_to_end(hip, tmp_path, monkeypatch, deg, scale, capsys):
     """`python main.py --ni --config ... --deg ... -i ...` (evaluation.sh style) on synthetic images with
     seeded random weights: images are written, PSNR is reported, exit code 0."""

@@ -167,4 +167,6 @@ def test_reference_simplified_loop_restatement():
         sys.modules.pop("datasets", None)
     x = torch.randn(1, 3, 8, 8)
     assert torch.equal(D.MeanUpsample(x, 4), sampler.mean_upsample(x, 4))
+    from oracle import operators as O
+    assert torch.equal(D.color2gray(x), O.color2gray(x)) and torch.equal(D.gray2color(x), O.gray2color(x))
     assert D.get_schedule_jump(100, 10, 3) == schedule.jump_times(100, 10, 3)
