@@ -59,6 +59,8 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_fuses_skip": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_spectral_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_float,
+                                        c_float, c_int32, c_void_p]),
     "ddnm_patchify_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_gn_apply_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),

@@ -537,6 +537,44 @@ extern "C" int ddnm_mul_planes_f32(const float* x, const float* table, int32_t p
     return 0;
 }
 
+// DDNM+ spectral weights of Deblurring (svd_operators.py:1016-1091), evaluated per spectral entry from the
+// UNSORTED, un-thresholded singular table s[p] = s1_i * s1_j (the reference's sort :962 and its inverse cancel):
+//   mode 0 (Lambda :1016-1040):        out = x * lambda(s[p])
+//   mode 1 (Lambda_noise :1042-1091):  out = x * d1(s[p]) + y * d2(s[p])
+// with inv = 1/s (0 if s == 0), thr = a*sigma_y*inv:
+//   sigma_t < thr: lambda = s*sigma_t*sqrt(1-eta^2)/a/sigma_y, d = (sigma_t*eta, 0)
+//   sigma_t > thr: lambda = 1, d = (sqrt(sigma_t^2 - a^2 sigma_y^2 inv^2), 0)
+//   s == 0 (and a tie): lambda = 1, d = (sigma_t*eta, sigma_t*sqrt(1-eta^2));  a == 0 or sigma_y == 0: no regime change
+__global__ __launch_bounds__(256) void spectral_mix_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ stab, int64_t plane_elems,
+                                                           float* __restrict__ out, int64_t total, float a, float sy,
+                                                           float st, float eta, float eta_c, int mode) {
+    const bool active = a != 0.f && sy != 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float s = stab[i % plane_elems];
+        const float inv = s == 0.f ? 0.f : 1.f / s;
+        float lam = 1.f, d1 = st * eta, d2 = st * eta_c;
+        if (active) {
+            const float thr = a * sy * inv;
+            if (st < thr) { lam = s * st * eta_c / a / sy; d2 = 0.f; }
+            if (st > thr) { d1 = sqrtf(st * st - a * a * (sy * sy) * (inv * inv)); d2 = 0.f; }
+            if (s == 0.f) { d1 = st * eta; d2 = st * eta_c; }
+        }
+        out[i] = mode == 0 ? x[i] * lam : x[i] * d1 + y[i] * d2;
+    }
+}
+
+extern "C" int ddnm_spectral_mix_f32(const float* x, const float* y, const float* singulars, int64_t plane_elems,
+                                     float* out, int64_t total, float a, float sigma_y, float sigma_t, float eta,
+                                     int32_t mode, void* stream) {
+    if (!x || !singulars || !out || plane_elems <= 0 || total <= 0 || (mode != 0 && mode != 1)) return DDNM_E_BADARG;
+    if (mode == 1 && !y) return DDNM_E_BADARG;
+    const float eta_c = (float)sqrt(1.0 - (double)eta * (double)eta);
+    DDNM_LAUNCH(spectral_mix_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, x, y, singulars, plane_elems, out,
+                total, a, sigma_y, sigma_t, eta, eta_c, mode);
+    return 0;
+}
+
 // out[b][i] = a * x[b*x_bstride + i] + b * y[b*chw + i]: eps <- eps[:, :3] - sqrt(1-abar) * grad  (svd_ddnm.py:51-52)
 __global__ __launch_bounds__(256) void axpby_strided_kernel(const float* __restrict__ x, int64_t x_bstride,
                                                             const float* __restrict__ y, float* __restrict__ out,

@@ -581,6 +581,8 @@ class Deblurring2D(A_functions):
             return A
         U1, S1, V1 = torch.svd(blur_matrix(kernel1), some=False)          # host-side setup like the reference ctor
         U2, S2, V2 = torch.svd(blur_matrix(kernel2), some=False)
+        # un-thresholded table s1_i * s2_j in spectral-plane order: what `_singulars_orig[_perm]` holds (:959,963)
+        self.S_orig = torch.matmul(S1.reshape(n, 1), S2.reshape(1, n)).reshape(n * n).contiguous().to(device)
         S1, S2 = S1.clone(), S2.clone()
         S1[S1 < self.ZERO] = 0
         S2[S2 < self.ZERO] = 0
@@ -629,6 +631,33 @@ class Deblurring(Deblurring2D):
     def __init__(self, kernel, channels, img_dim, device, ZERO=3e-2):
         self.ZERO = ZERO
         super().__init__(kernel, kernel, channels, img_dim, device)
+
+    def _spectral_mix(self, x, y, a, sigma_y, sigma_t, eta, mode):
+        out = torch.empty_like(x)
+        check(_lib.lib().ddnm_spectral_mix_f32(_p(x), _p(y), _p(self.S_orig), self.img_dim ** 2, _p(out), x.numel(),
+                                               float(a), float(sigma_y), float(sigma_t), float(eta), mode,
+                                               ops._stream()), "ddnm_spectral_mix_f32")
+        return out
+
+    def _two_sided(self, L, x, Rt_rows):
+        """L . X . R for every plane (Rt_rows = R^T row-major)."""
+        bc, n = x.numel() // self.img_dim ** 2, self.img_dim
+        t1 = torch.empty(bc, n, n, dtype=torch.float32, device=x.device)
+        ops.bgemm(L, x, t1, n, n, n, lda=n, ldb=n, ldc=n, transb=False, batch=bc, sB=(n * n, 0), sC=(n * n, 0))
+        out = torch.empty(x.shape[0], x.numel() // x.shape[0], dtype=torch.float32, device=x.device)
+        ops.bgemm(t1, Rt_rows, out, n, n, n, lda=n, ldb=n, ldc=n, transb=True, batch=bc, sA=(n * n, 0), sC=(n * n, 0))
+        return out
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:1016-1040
+        """V diag(lambda) V^T vec, lambda from the un-thresholded singular values; the reference's sort and its
+        inverse cancel, so the weights are applied directly in the (V1^T X V1) plane."""
+        spec = self._two_sided(self.V1t, _img(vec, self.channels, self.img_dim), self.V1t)
+        spec = self._spectral_mix(spec, None, a, sigma_y, sigma_t, eta, 0)
+        return self._two_sided(self.V1, spec, self.V1)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :1042-1091 (raw entries fed to V)
+        mixed = self._spectral_mix(_flat(vec), _flat(epsilon), a, sigma_y, sigma_t, eta, 1)
+        return self._two_sided(self.V1, mixed, self.V1)
 
 
 def gaussian_taps(sigma, radius):

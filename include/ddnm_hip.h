@@ -273,6 +273,12 @@ int ddnm_site_spectral_f32(const float* x, const float* y, const float* V, int32
 int ddnm_mul_planes_f32(const float* x, const float* table, int32_t planes_table, int64_t plane_elems, float* out,
                         int64_t total, void* stream);
 
+/* DDNM+ spectral weights of Deblurring (svd_operators.py:1016-1091) applied in the (V1^T . V1) spectral plane:
+ * mode 0: out = x .* lambda(s[p]); mode 1: out = x .* d1(s[p]) + y .* d2(s[p]); s = un-thresholded s1_i*s1_j table
+ * [plane_elems], p = i % plane_elems; lambda/d1/d2 as in svd_ddnm.py:121-131 (see ddnm_step.hip). */
+int ddnm_spectral_mix_f32(const float* x, const float* y, const float* singulars, int64_t plane_elems, float* out,
+                          int64_t total, float a, float sigma_y, float sigma_t, float eta, int32_t mode, void* stream);
+
 /* Stand-alone operator kernels (A and A^+ of functions/svd_operators.py, direct form). */
 int ddnm_op_avgpool_f32(const float* x, float* y, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);
 int ddnm_op_upsample_f32(const float* y, float* x, int32_t BC, int32_t H, int32_t W, int32_t r, void* stream);

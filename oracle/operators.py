@@ -423,6 +423,40 @@ class Deblurring2D:
 class Deblurring(Deblurring2D):
     def __init__(self, kernel, channels, img_dim):
         super().__init__(kernel, kernel, channels, img_dim)
+        _, S, _ = torch.svd(blur_matrix(kernel.float().cpu(), img_dim), some=False)
+        # `_singulars_orig` (:959,963): un-thresholded products, carried through the same permutation as the sorted
+        # values -- in spectral-plane order the permutation drops out
+        self.S_orig = torch.matmul(S.reshape(-1, 1), S.reshape(1, -1))
+
+    def _weights(self, a, sigma_y, sigma_t, eta):
+        """lambda, d1, d2 per spectral entry, the tensor expressions of :1021-1031 and :1049-1072."""
+        s = self.S_orig
+        inv = torch.where(s == 0, torch.zeros_like(s), 1.0 / s)
+        lam = torch.ones_like(s)
+        d1 = torch.ones_like(s) * sigma_t * eta
+        d2 = torch.ones_like(s) * sigma_t * (1 - eta ** 2) ** 0.5
+        if a != 0 and sigma_y != 0:
+            c = (sigma_t < a * sigma_y * inv) * 1.0
+            lam = lam * (1 - c) + c * (s * sigma_t * (1 - eta ** 2) ** 0.5 / a / sigma_y)
+            d1 = d1 * (1 - c) + c * sigma_t * eta
+            d2 = d2 * (1 - c)
+            c = (sigma_t > a * sigma_y * inv) * 1.0
+            d1 = d1 * (1 - c) + torch.sqrt(c * (sigma_t ** 2 - a ** 2 * sigma_y ** 2 * inv ** 2))
+            d2 = d2 * (1 - c)
+            c = (s == 0) * 1.0
+            d1 = d1 * (1 - c) + c * sigma_t * eta
+            d2 = d2 * (1 - c) + c * sigma_t * (1 - eta ** 2) ** 0.5
+        return lam, d1, d2
+
+    def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # :1016-1040
+        lam = self._weights(a, sigma_y, sigma_t, eta)[0]
+        T = self.V1.T @ self._planes(vec) @ self.V1
+        return (self.V1 @ (T * lam) @ self.V1.T).reshape(vec.shape[0], -1)
+
+    def Lambda_noise(self, vec, a, sigma_y, sigma_t, eta, epsilon):        # :1042-1091: vec / epsilon enter V raw
+        _, d1, d2 = self._weights(a, sigma_y, sigma_t, eta)
+        M = self._planes(vec) * d1 + self._planes(epsilon) * d2
+        return (self.V1 @ M @ self.V1.T).reshape(vec.shape[0], -1)
 
 
 def gaussian_taps(sigma, radius):

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout 600 python -m pytest tests/test_cs.py tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_ddnm_plus.py tests/test_deblur.py tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -8

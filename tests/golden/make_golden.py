@@ -182,6 +182,41 @@ def make_plus():
                                                       classes=None, config=cfg)
         out[f"{name}_x"], out[f"{name}_x0"], out[f"{name}_y"] = xs[0].numpy(), x0s[0].numpy(), y.numpy()
     np.savez_compressed(os.path.join(HERE, "ddnm_plus_small.npz"), **out)
+    make_plus_deblur(ns, R, ref, cfg, n_it)
+
+
+def make_plus_deblur(ns=None, R=None, ref=None, cfg=None, n_it=None):
+    """Same DDNM+ case for Deblurring (the only blur operator with Lambda / Lambda_noise, :1016-1091), own file."""
+    if ns is None:
+        ns = ref_import.load()
+        R = ns.svd_operators
+        cfg, sd = cases.celeba_net("small")
+        ref = ns.models.Model(cfg)
+        ref.load_state_dict(sd)
+        ref.eval()
+        cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 20, 2, 2
+        n_it = len(schedule.jump_times(20, 2, 2)) - 1
+    d = cfg.data.image_size
+    out = {}
+    for name in ("deblur_uni", "deblur_gauss"):
+        x_orig, x_T, tape = cases.sampler_case(cfg, 2, n_it)
+        op = ref_operator(R, name, d)
+        y = op.A(x_orig)
+        gy = torch.Generator().manual_seed(cases.SEED + 9)
+        y = y + 0.2 * torch.randn(y.shape, generator=gy)
+        with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+            xs, x0s = ns.svd_ddnm.ddnm_plus_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, 0.2, cls_fn=None,
+                                                      classes=None, config=cfg)
+        out[f"{name}_x"], out[f"{name}_x0"], out[f"{name}_y"] = xs[0].numpy(), x0s[0].numpy(), y.numpy()
+        # operator-level vectors in two regimes of the threshold
+        g = torch.Generator().manual_seed(3)
+        v, e = torch.randn(2, 3 * d * d, generator=g), torch.randn(2, 3 * d * d, generator=g)
+        for tag, tn, sy in (("hi", 990, 0.4), ("mid", 500, 0.4), ("lo", 10, 0.4)):
+            atn = schedule.alpha_bar(cases.betas(), tn)
+            a, st = atn.sqrt(), (1 - atn).sqrt()
+            out[f"{name}_lambda_{tag}"] = op.Lambda(v.clone(), a, sy, st, 0.85).numpy()
+            out[f"{name}_lambda_noise_{tag}"] = op.Lambda_noise(v.clone(), a, sy, st, 0.85, e.clone()).numpy()
+    np.savez_compressed(os.path.join(HERE, "ddnm_plus_deblur.npz"), **out)
 
 
 def make_adm():
@@ -225,12 +260,15 @@ def main():
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
+    ap.add_argument("--plus-deblur-only", action="store_true", help="only (re)generate the DDNM+ deblurring goldens")
     ap.add_argument("--cs-only", action="store_true", help="only (re)generate the block-based CS goldens")
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     args = ap.parse_args()
     if args.classifier_only:
         return make_classifier()
+    if args.plus_deblur_only:
+        return make_plus_deblur()
     if args.cs_only:
         return make_cs()
     if args.deblur_only:
