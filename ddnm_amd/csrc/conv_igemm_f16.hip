@@ -204,8 +204,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     }
     // ---- fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's
     // raw input at the centre tap (see conv_igemm_f32.hip)
-    if (d.skip0 != nullptr && slice == 0) {
-        const int SCin = d.SC0 + d.SC1, nsk = SCin / KC16;
+    if (d.skip0 != nullptr) {
+        // split-K launches share the shortcut's chunks like the main ones (slice 0 alone would run 2-3x longer)
+        const int SCin = d.SC0 + d.SC1, nsk_all = SCin / KC16;
+        const int s_begin = (int)((long)nsk_all * slice / p.ksplit), s_end = (int)((long)nsk_all * (slice + 1) / p.ksplit);
         const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin + c8 * 8;
         // the raw input is fp32: thread -> (float4 column sc of 16, interior pixels srow + 32*i), staged at the
         // pixel's halo position so that mfma_tap(4) (centre tap) reads it
@@ -234,8 +236,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             for (int i = 0; i < BR; ++i)
                 b_st[i] = *reinterpret_cast<const uint4*>(swbase + (size_t)(BROWS_PER_PASS * i) * SCin + cb);
         };
-        prefetch_skip(0);
-        for (int ch = 0; ch < nsk; ++ch) {
+        if (s_begin < s_end) prefetch_skip(s_begin);
+        for (int ch = s_begin; ch < s_end; ++ch) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < SR; ++i) {
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             }
             stage_b(0);
             __syncthreads();
-            if (ch + 1 < nsk) prefetch_skip(ch + 1);
+            if (ch + 1 < s_end) prefetch_skip(ch + 1);
             mfma_tap(4, 0);
         }
     }

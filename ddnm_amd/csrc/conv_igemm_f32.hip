@@ -225,8 +225,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
     // ---- fused 1x1 shortcut (nin_shortcut / skip_connection of a residual block): extra K chunks that read
     // the block's RAW input (no GroupNorm) at the centre tap and accumulate into the same tile, so the
     // shortcut needs neither its own launch nor an HBM round trip of its output.
-    if (d.skip0 != nullptr && slice == 0) {
-        const int SCin = d.SC0 + d.SC1, nsk = SCin / KC;
+    if (d.skip0 != nullptr) {
+        // split-K launches share the shortcut's chunks like the main ones (slice 0 alone would run 2-3x longer)
+        const int SCin = d.SC0 + d.SC1, nsk_all = SCin / KC;
+        const int s_begin = (int)((long)nsk_all * slice / p.ksplit), s_end = (int)((long)nsk_all * (slice + 1) / p.ksplit);
         const float* swbase = d.skip_weight + (size_t)(n_tile * BN + prow) * SCin + c4 * 4;
         auto prefetch_skip = [&](int ch) {
             const int cb = ch * KC;
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 #pragma unroll
             for (int i = 0; i < BR; ++i) b_st[i] = *reinterpret_cast<const f32x4*>(swbase + (size_t)(32 * i) * SCin + cb);
         };
-        prefetch_skip(0);
-        for (int ch = 0; ch < nsk; ++ch) {
+        if (s_begin < s_end) prefetch_skip(s_begin);
+        for (int ch = s_begin; ch < s_end; ++ch) {
             __syncthreads();
             stage_halo(false);
             stage_b(0);
             __syncthreads();
-            if (ch + 1 < nsk) prefetch_skip(ch + 1);
+            if (ch + 1 < s_end) prefetch_skip(ch + 1);
             mfma_tap(4, 0);                      // centre tap: the tile's own pixels
         }
     }

@@ -35,6 +35,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []          # (variant, flops, start_event, end_event)
+        self.shapes = []           # per record: (B, Ho, Wo, Cin, Cout, k, stride, ups, skipC, gn, res)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -204,7 +205,10 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         e0.record()
         check(fn_run(ctypes.byref(d), _stream()), "ddnm_conv2d")
         e1.record()
-        _timer.records.append((variant, 2.0 * B * Ho * Wo * cout * ksize * ksize * (C0 + C1), e0, e1))
+        flops = 2.0 * B * Ho * Wo * cout * (ksize * ksize * (C0 + C1) + d.SC0 + d.SC1)      # + fused 1x1 shortcut
+        _timer.records.append((variant, flops, e0, e1))
+        _timer.shapes.append((B, Ho, Wo, C0 + C1, cout, ksize, stride, int(ups), d.SC0 + d.SC1, gn is not None,
+                              res is not None))
     if emit_stats:
         return Act(out, stats, tiles)
     return out

@@ -295,12 +295,11 @@ def test_groupnorm_from_conv_epilogue_stats(hip, B, C0, C1, H):
 
 
 @pytest.mark.parametrize("f16", [False, True])
-def test_conv_fused_shortcut(hip, f16):
+@pytest.mark.parametrize("B,C,C0,C1,H", [(4, 128, 128, 128, 32),      # plain launch
+                                         (2, 256, 256, 128, 16)])     # split-K launch: shortcut chunks are shared too
+def test_conv_fused_shortcut(hip, f16, B, C, C0, C1, H):
     """conv2(3x3, GN+swish prologue) + 1x1 shortcut over the concat of two raw tensors, one launch."""
     from ddnm_amd import ops
-    B, C, C0, C1, H = 4, 128, 128, 128, 32
-    if f16:
-        B, H = 4, 32                       # 4*1024/256 tiles
     h = gen(B, C, H, H, seed=60)
     a, b2 = gen(B, C0, H, H, seed=61), gen(B, C1, H, H, seed=62)
     w2 = gen(C, C, 3, 3, seed=63, scale=(9 * C) ** -0.5)
