@@ -61,6 +61,13 @@ PROTOTYPES = {
     "ddnm_conv2d_f32_fuses_skip": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_spectral_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_float, c_float, c_float,
                                         c_float, c_int32, c_void_p]),
+    "ddnm_hq_x0_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_float, c_float, c_int32,
+                                 c_void_p]),
+    "ddnm_hq_project_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "ddnm_copy_rect_f32": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_hq_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                     c_float, c_void_p]),
     "ddnm_patchify_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_gn_apply_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),

@@ -21,11 +21,13 @@ extern "C" int ddnm_gn_nchunk(int32_t HW, int32_t C) {
 
 __global__ void gn_stats_kernel(const float* __restrict__ src0, const float* __restrict__ src1, int HW, int C0,
                                 int C1, int groups, double* __restrict__ partial, int nchunk, int pix_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // [2][blockDim]
+    // per-thread, per-channel fp32 sums over <= 64 pixels -> LDS [2][blockDim][4]; then one thread per group adds
+    // its channels in fp64 (any group size: ADM nets have 1 .. 32 channels per group)
+    extern __shared__ __attribute__((aligned(16))) float redf[];
     const int C = C0 + C1, C4 = C >> 2;
     const int rows = blockDim.x / C4, active = rows * C4;
     const int tid = threadIdx.x, chunk = blockIdx.x, b = blockIdx.y;
-    float s = 0.f, ss = 0.f;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     if (tid < active) {
         const int c4 = tid % C4, prow = tid / C4;
         const int c = c4 * 4;
@@ -36,21 +38,24 @@ __global__ void gn_stats_kernel(const float* __restrict__ src0, const float* __r
         const int p_end = min(HW, (chunk + 1) * pix_per_chunk);
         for (int p = chunk * pix_per_chunk + prow; p < p_end; p += rows) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * cs);
-            s += (v.x + v.y) + (v.z + v.w);
-            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            s += v;
+            ss += v * v;
         }
     }
-    red[tid] = (double)s;
-    red[blockDim.x + tid] = (double)ss;
+    f32x4* r4 = reinterpret_cast<f32x4*>(redf);
+    r4[tid] = s;
+    r4[blockDim.x + tid] = ss;
     __syncthreads();
     if (tid < groups) {
-        const int q = (C / groups) >> 2;            // float4 columns per group
+        const int cpg = C / groups;
+        const float* sum = redf;
+        const float* sq = redf + 4 * blockDim.x;
         double a = 0.0, a2 = 0.0;
         for (int r = 0; r < rows; ++r)
-            for (int j = 0; j < q; ++j) {
-                const int t = r * C4 + tid * q + j;
-                a += red[t];
-                a2 += red[blockDim.x + t];
+            for (int j = 0; j < cpg; ++j) {
+                const int t = r * C + tid * cpg + j;        // row r holds channels [0, C) as C4 float4s
+                a += (double)sum[t];
+                a2 += (double)sq[t];
             }
         double* o = partial + (((size_t)b * nchunk + chunk) * groups + tid) * 2;
         o[0] = a;
@@ -62,11 +67,11 @@ extern "C" int ddnm_gn_stats_f32(const float* src0, const float* src1, int32_t B
                                  int32_t groups, double* partial, int32_t nchunk, void* stream) {
     if (!src0 || !partial || B <= 0 || HW <= 0 || C0 <= 0 || (C1 > 0 && !src1)) return DDNM_E_BADARG;
     const int C = C0 + C1;
-    if (groups <= 0 || groups > 64 || C % (groups * 4) || C0 % 4 || C / 4 > 1024) return DDNM_E_SHAPE;
+    if (groups <= 0 || groups > 64 || C % groups || C % 4 || C0 % 4 || C / 4 > 1024) return DDNM_E_SHAPE;
     const int C4 = C / 4, bd = gn_block_dim(C4);
     const int rows = bd / C4, pix = rows * GN_PIX_PER_THREAD;
     if (nchunk != (HW + pix - 1) / pix) return DDNM_E_BADARG;
-    DDNM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), (hipStream_t)stream, src0,
+    DDNM_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * 4 * sizeof(float), (hipStream_t)stream, src0,
                        src1, HW, C0, C1, groups, partial, nchunk, pix);
     return 0;
 }

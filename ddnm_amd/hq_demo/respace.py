@@ -1,0 +1,37 @@
+"""Timestep respacing of the hq_demo sampler (hq_demo/guided_diffusion/respace.py:23-122): host-side float64."""
+import numpy as np
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """Set of retained steps: `section_counts` = "N", "a,b,c" (equal sections, evenly strided inside each) or
+    "ddimN" (fixed integer stride), respace.py:23-77."""
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                if len(range(0, num_timesteps, stride)) == want:
+                    return set(range(0, num_timesteps, stride))
+            raise ValueError(f"cannot create exactly {want} steps with an integer stride")
+        section_counts = [int(v) for v in section_counts.split(",")]
+    elif isinstance(section_counts, int):
+        section_counts = [section_counts]
+    if len(section_counts) == 1 and section_counts[0] > num_timesteps:
+        return set(np.linspace(start=0, stop=num_timesteps, num=section_counts[0]))
+    base, extra = divmod(num_timesteps, len(section_counts))
+    steps, start = [], 0
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        steps.extend(start + round(k * stride) for k in range(count))
+        start += size
+    return set(steps)
+
+
+def respaced_betas(betas, use_timesteps):
+    """(new_betas, timestep_map): betas of the process that visits only `use_timesteps` (respace.py:93-104)."""
+    acp = np.cumprod(1.0 - np.asarray(betas, dtype=np.float64))
+    keep = sorted(int(t) for t in use_timesteps)
+    prev = np.concatenate([[1.0], acp[keep][:-1]])
+    return 1.0 - acp[keep] / prev, keep

@@ -306,6 +306,23 @@ int ddnm_wh_scatter_f32(const float* y, const int32_t* perm, float* planes, int3
  * Vt_small / V_small (:108-109) then act as one ddnm_bgemm_f32 over all patches.  D % ps == 0, ps % 4 == 0. */
 int ddnm_patchify_f32(const float* src, float* dst, int32_t planes, int32_t D, int32_t ps, int32_t inverse, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * hq_demo sampler: DDPM posterior step with the DDNM core and the mask-shift tiles
+ * (hq_demo/guided_diffusion/gaussian_diffusion.py:246-404,430-487,664-746).
+ * ------------------------------------------------------------------------- */
+/* x0 = clamp?(c_recip*x_t - c_recipm1*eps, -1, 1); eps row b at eps + b*eps_bstride (first 3 of the 6 output channels) */
+int ddnm_hq_x0_f32(const float* xt, const float* eps, int64_t eps_bstride, float* x0, int32_t B, int64_t chw,
+                   float c_recip, float c_recipm1, int32_t clip, void* stream);
+/* x0_hat = lambda*A^+y + x0 - lambda*A^+A x0 (Eq. 17, :339) */
+int ddnm_hq_project_f32(const float* x0, const float* apy, const float* apax0, float* x0_hat, int64_t n, float lam,
+                        void* stream);
+/* dst[p][dy+i][dx+j] = src[p][sy+i][sx+j], i < h, j < w, for `planes` planes of [Hs][Ws] / [Hd][Wd] */
+int ddnm_copy_rect_f32(const float* src, int32_t Hs, int32_t Ws, int32_t sy, int32_t sx, float* dst, int32_t Hd, int32_t Wd,
+                       int32_t dy, int32_t dx, int32_t planes, int32_t h, int32_t w, void* stream);
+/* out = (coef1*x0_hat + coef2*x_t [+ gamma*grad]) + noise_scale*noise; grad may be NULL */
+int ddnm_hq_sample_f32(const float* x0_hat, const float* xt, const float* grad, const float* noise, float* out, int64_t n,
+                       float coef1, float coef2, float gamma, float noise_scale, void* stream);
+
 /* inverse_data_transform + per-image MSE (datasets/__init__.py:218-227; diffusion.py:599-602):
  * img = clamp((x+1)/2, 0, 1); mse[b] = mean((img - clamp((x_orig+1)/2,0,1))^2) */
 int ddnm_finalize_psnr_f32(const float* x, const float* x_orig, float* img /* may be NULL */, double* sse /* [B], zeroed by callee */,

@@ -104,7 +104,8 @@ def test_conv_rejects_bad_shapes(hip):
 
 # ------------------------------------------------------------------ GroupNorm
 @pytest.mark.parametrize("B,C0,C1,H", [(2, 128, 0, 32), (2, 256, 128, 16), (1, 512, 256, 8), (3, 1024, 0, 8),
-                                       (1, 128, 0, 64)])
+                                       (1, 128, 0, 64),
+                                       (2, 32, 0, 16), (2, 64, 32, 16), (1, 192, 0, 8)])      # 1, 3, 6 channels / group
 def test_groupnorm_affine(hip, B, C0, C1, H):
     from ddnm_amd import ops
     a = gen(B, C0, H, H, seed=20) * 2 + 0.7
