@@ -230,3 +230,75 @@ static __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const Co
     }
 }
 
+// Same reduction for launches whose consumer is a GroupNorm: one workgroup per (image, pixel tile), every thread owns
+// one float4 channel column, so the per-(tile, channel) sum / sum of squares of the FINAL values come for free
+// (layout of conv_epilogue's stats_out) and the low-resolution layers need no stand-alone statistics pass either.
+static __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const ConvArgs p, int tpi) {
+    __shared__ f32x4 red[2][256];
+    const ddnm_conv_desc& d = p.d;
+    const int c4n = d.Cout >> 2;
+    const int rows = 256 / c4n, active = rows * c4n;
+    const int hw = d.Ho * d.Wo, P = hw / tpi;
+    const int b = blockIdx.x / tpi, t = blockIdx.x - b * tpi;
+    const size_t slab4 = (size_t)d.B * hw * c4n;
+    const int tid = threadIdx.x;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (tid < active) {
+        const int c4 = tid % c4n, prow = tid / c4n, n = c4 * 4;
+        f32x4 add = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) add = add + *reinterpret_cast<const f32x4*>(d.bias + n);
+        if (d.badd) add = add + *reinterpret_cast<const f32x4*>(d.badd + (size_t)b * d.badd_stride + n);
+        for (int pp = prow; pp < P; pp += rows) {
+            const int p2 = t * P + pp;
+            const size_t i = ((size_t)b * hw + p2) * c4n + c4;
+            f32x4 v = reinterpret_cast<const f32x4*>(p.ws)[i];
+            for (int k = 1; k < p.ksplit; ++k) v = v + reinterpret_cast<const f32x4*>(p.ws)[i + k * slab4];
+            v = v + add;
+            if (d.res) {
+                if (d.res_ups) {
+                    const int oy = p2 / d.Wo, ox = p2 - oy * d.Wo;
+                    v = v + *reinterpret_cast<const f32x4*>(d.res + (((size_t)b * (d.Ho >> 1) + (oy >> 1)) * (d.Wo >> 1) + (ox >> 1)) * d.Cout + n);
+                } else {
+                    v = v + reinterpret_cast<const f32x4*>(d.res)[i];
+                }
+            }
+            reinterpret_cast<f32x4*>(d.out)[i] = v;
+            s += v;
+            ss += v * v;
+        }
+    }
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
+    if (tid < c4n) {
+        for (int r = 1; r < rows; ++r) { s += red[0][r * c4n + tid]; ss += red[1][r * c4n + tid]; }
+        float* o = d.stats_out + ((size_t)blockIdx.x * d.Cout + tid * 4) * 2;
+        f32x4 lo = {s.x, ss.x, s.y, ss.y}, hi = {s.z, ss.z, s.w, ss.w};
+        reinterpret_cast<f32x4*>(o)[0] = lo;
+        reinterpret_cast<f32x4*>(o)[1] = hi;
+    }
+}
+
+// pixel tiles per image of the statistics-emitting reduction (0: this launch cannot emit them)
+static inline int splitk_stats_tiles(const ddnm_conv_desc* d) {
+    const int hw = d->Ho * d->Wo;
+    if (d->out_nchw || d->Cout % 4 || d->Cout > 1024 || hw % 4) return 0;
+    int tpi = hw / 4 < 32 ? hw / 4 : 32;
+    while (tpi > 1 && hw % tpi) --tpi;
+    return tpi;
+}
+
+static inline int launch_splitk_reduce(const ConvArgs& p, hipStream_t s) {
+    const ddnm_conv_desc& d = p.d;
+    if (d.stats_out) {
+        const int tpi = splitk_stats_tiles(&d);
+        if (tpi <= 0) return DDNM_E_SHAPE;
+        DDNM_LAUNCH(conv_splitk_reduce_stats_kernel, dim3(d.B * tpi), dim3(256), 0, s, p, tpi);
+        return 0;
+    }
+    const size_t total4 = (size_t)d.B * d.Ho * d.Wo * d.Cout / 4;
+    const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+    DDNM_LAUNCH(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p, total4);
+    return 0;
+}
+

@@ -298,7 +298,7 @@ extern "C" int64_t ddnm_conv3x3_f16_workspace_floats(const ddnm_conv_desc* d) {
 extern "C" int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d) {
     PlanF16 pl;
     if (!d || !plan_f16(d, &pl)) return DDNM_E_SHAPE;
-    return pl.ksplit > 1 ? 0 : d->Ho * d->Wo / pl.BM;
+    return pl.ksplit > 1 ? splitk_stats_tiles(d) : d->Ho * d->Wo / pl.BM;
 }
 
 extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
@@ -317,9 +317,11 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     }
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
-        if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;
+        if (!d->workspace || d->workspace_floats < need) {
+            if (d->stats_out) return DDNM_E_BADARG;
+            pl.ksplit = 1;
+        }
     }
-    if (d->stats_out && pl.ksplit > 1) return DDNM_E_SHAPE;
     ConvArgs p;
     p.d = *d;
     p.Cin = d->C0 + d->C1;
@@ -339,10 +341,6 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     } else {
         DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
     }
-    if (pl.ksplit > 1) {
-        const size_t total4 = (size_t)d->B * d->Ho * d->Wo * d->Cout / 4;
-        const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        DDNM_LAUNCH(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p, total4);
-    }
+    if (pl.ksplit > 1) return launch_splitk_reduce(p, s);
     return 0;
 }

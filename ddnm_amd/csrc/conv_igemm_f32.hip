@@ -431,7 +431,8 @@ extern "C" int ddnm_conv2d_f32_fuses_skip(const ddnm_conv_desc* d) {
 extern "C" int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d) {
     ConvPlan pl;
     if (!d || !make_plan(d, &pl)) return DDNM_E_SHAPE;
-    if (pl.ksplit > 1 || d->out_nchw) return 0;         // split-K / NCHW launches do not emit statistics
+    if (d->out_nchw) return 0;                          // NCHW launches do not emit statistics
+    if (pl.ksplit > 1) return splitk_stats_tiles(d);    // ... split-K launches emit them from the reduction pass
     return d->Ho * d->Wo / pl.BM;
 }
 
@@ -467,9 +468,12 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
     }
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout;
-        if (!d->workspace || d->workspace_floats < need) pl.ksplit = 1;      // no scratch: run unsplit
+        if (!d->workspace || d->workspace_floats < need) {
+            if (d->stats_out) return DDNM_E_BADARG;       // the caller sized stats_out for the split plan
+            pl.ksplit = 1;                                // no scratch: run unsplit
+        }
     }
-    if (d->stats_out && (pl.ksplit > 1 || d->out_nchw)) return DDNM_E_SHAPE;  // see ddnm_conv2d_f32_stats_tiles
+    if (d->stats_out && d->out_nchw) return DDNM_E_SHAPE;                     // see ddnm_conv2d_f32_stats_tiles
     ConvArgs p;
     p.d = *d;
     p.Cin = d->C0 + d->C1;
@@ -493,11 +497,6 @@ extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
         default: return DDNM_E_BADARG;
     }
     DDNM_LAUNCH_CHECK();
-    if (pl.ksplit > 1) {
-        const size_t total4 = (size_t)d->B * d->Ho * d->Wo * d->Cout / 4;
-        const unsigned g = (unsigned)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p, total4);
-        DDNM_LAUNCH_CHECK();
-    }
+    if (pl.ksplit > 1) return launch_splitk_reduce(p, s);
     return 0;
 }

@@ -267,16 +267,20 @@ def test_renoise_and_finalize(hip):
 
 
 # ------------------------------------------------------------------ GroupNorm statistics from the conv epilogue
-@pytest.mark.parametrize("B,C0,C1,H", [(4, 256, 0, 64), (4, 256, 256, 64), (8, 128, 128, 64), (2, 128, 384, 128)])
+@pytest.mark.parametrize("B,C0,C1,H", [(4, 256, 0, 64), (4, 256, 256, 64), (8, 128, 128, 64), (2, 128, 384, 128),
+                                       (2, 256, 0, 16), (1, 512, 128, 8)])       # split-K launches: stats from the reduction
 def test_groupnorm_from_conv_epilogue_stats(hip, B, C0, C1, H):
     """The producing convolutions emit per-(tile, channel) partials; the consumer's GroupNorm affine is built
     from them (two sources = skip concat, possibly with different tilings) without re-reading the tensors."""
     from ddnm_amd import ops
     x = gen(B, 128, H, H, seed=50)
     w0 = gen(C0, 128, 3, 3, seed=51, scale=0.04)
-    a = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w0.cuda()), C0, 3, emit_stats=True)
-    ref0 = F.conv2d(x, w0, None, padding=1)
+    bias0, r0 = gen(C0, seed=55), gen(B, C0, H, H, seed=56)
+    a = ops.conv2d(nhwc(x).cuda(), ops.pack_conv_weight(w0.cuda()), C0, 3, emit_stats=True, bias=bias0.cuda(),
+                   res=nhwc(r0).cuda())
+    ref0 = F.conv2d(x, w0, bias0, padding=1) + r0
     assert a.stats is not None and a.tiles > 0
+    assert rel(nchw(a.t.cpu()), ref0) < 3e-6
     a1, ref1 = None, None
     if C1:
         w1 = gen(C1, 128, 1, 1, seed=52, scale=0.1)
