@@ -13,8 +13,9 @@ from ddnm_amd._lib import ConvDesc  # noqa: E402
 
 CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out")
-VARIANTS = {"base": [], "no_restage": ["-DDDNM_PROBE16_NO_RESTAGE"], "no_tap_barrier": ["-DDDNM_PROBE16_NO_TAP_BARRIER"],
-            "neither": ["-DDDNM_PROBE16_NO_RESTAGE", "-DDDNM_PROBE16_NO_TAP_BARRIER"]}
+VARIANTS = {"base": [], "no_res_fold": ["-DDDNM_PROBE_NO_RES_FOLD"]}
+if len(sys.argv) > 1:
+    VARIANTS = {"base": [], **{f"v{i}": a.split() for i, a in enumerate(sys.argv[1:])}}
 os.makedirs(OUT, exist_ok=True)
 libs = {}
 for n, fl in VARIANTS.items():
@@ -27,8 +28,10 @@ for n, fl in VARIANTS.items():
     libs[n] = lib
 dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
+wsb = torch.empty(64 << 20, device=dev)
 for name, B, C, H, gn, res in [("warm", 4, 256, 256, 1, 1), ("256@256 gn res", 4, 256, 256, 1, 1), ("256@256 plain", 4, 256, 256, 0, 0),
-                               ("512@128 gn res", 4, 512, 128, 1, 1), ("512@64 gn res", 4, 512, 64, 1, 1)]:
+                               ("256@256 res", 4, 256, 256, 0, 1), ("512@128 gn res", 4, 512, 128, 1, 1), ("512@128 res", 4, 512, 128, 0, 1),
+                               ("512@64 gn res", 4, 512, 64, 1, 1), ("1024@32 res", 4, 1024, 32, 0, 1)]:
     a = torch.randn(B, H, H, C, device=dev)
     w = (torch.randn(C, 9, C, device=dev) * 0.02).half()
     bias = torch.randn(C, device=dev)
@@ -41,6 +44,7 @@ for name, B, C, H, gn, res in [("warm", 4, 256, 256, 1, 1), ("256@256 gn res", 4
     d.gn_scale, d.gn_shift = (sc.data_ptr(), sh.data_ptr()) if gn else (None, None)
     d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, H, H, C, 0, C
     d.ksize, d.stride, d.pad, d.Ho, d.Wo, d.gn_silu = 3, 1, 1, H, H, 1
+    d.workspace, d.workspace_floats = wsb.data_ptr(), wsb.numel()
     flops = 2.0 * B * H * H * C * 9 * C
     row = []
     for n, lib in libs.items():

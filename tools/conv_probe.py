@@ -21,7 +21,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 VARIANTS = {
     "dbuf": [],
-
+    "nosched": ["-DDDNM_PROBE_NO_SCHED_BARRIER"],
 }
 
 # (name, B, C0, C1, Cout, H (input, pre-upsample), k, stride, ups, gn, res, tile)
