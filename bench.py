@@ -131,6 +131,7 @@ def bench_adm(args, ddist, rank, world, dev):
                                  if len(v) > 1 else (1.0 + 0.1 * torch.randn(v, generator=gsd) if k.endswith("weight")
                                                      else 0.05 * torch.randn(v, generator=gsd)))
                              for k, v in clf.state_dict_shapes().items()})
+        clf.convert_to_fp16()                  # imagenet_256_cc.yml: classifier_use_fp16 true
         cls_fn = make_cond_fn(clf, 1.0)
     betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
                                                num_diffusion_timesteps=1000)).float().to(dev)
@@ -178,7 +179,7 @@ def bench_adm(args, ddist, rank, world, dev):
                                     "c4": "imagenet_256.yml inpainting, time-travel l=10 r=3 (280 NFE + 180 re-noise), "
                                           "batch 4 per GPU (BASELINE configs[3] shard)",
                                     "c5": "imagenet_256_cc.yml cs_walshhadamard ratio 0.25, class-conditional ADM + classifier "
-                                          "guidance (class 951, scale 1.0; classifier fwd + input-gradient in fp32), batch 8 "
+                                          "guidance (class 951, scale 1.0; classifier fwd + input-gradient on fp16 MFMA operands), batch 8 "
                                           "on 1 GPU (BASELINE configs[4])"}[args.workload],
                        "global_batch": B * world, "nfe_per_image": nfe},
             "whole_loop_tflops_per_gpu": round(tfl, 1), "finite": bool(torch.isfinite(out).all())}

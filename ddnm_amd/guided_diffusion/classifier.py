@@ -23,6 +23,7 @@ from .._lib import check
 
 GN_EPS = 1e-5
 CIN_PAD = 32
+GRAD_SCALE_FP16 = 1024.0        # see EncoderUNetModel.convert_to_fp16
 
 
 def _p(t):
@@ -90,6 +91,7 @@ class EncoderUNetModel:
                     off += 2 * L[2]
         self.film_total = off
         self.w = None
+        self.use_fp16 = False          # set by convert_to_fp16(), like the reference's runner (diffusion.py:176-177)
         self._ws = None
 
     def _walk(self):
@@ -105,8 +107,27 @@ class EncoderUNetModel:
         return self
 
     def convert_to_fp16(self):
-        """Accepted (diffusion.py:176-177); the classifier and its gradient are evaluated in fp32 here."""
+        """`classifier.convert_to_fp16()` (diffusion.py:176-177, unet.py:817-823): the 3x3 convolutions of the
+        torso -- forward AND the data-gradient convolutions of the backward pass -- run on fp16 MFMA operands with
+        fp32 accumulation (csrc/conv_igemm_f16.hip); GroupNorm, attention, the pool and every gradient tensor in HBM
+        stay fp32.  The backward pass is linear in d(logits), so it is evaluated on 2^10 * d(logits) and rescaled at
+        the end: activation gradients of ~1e-6 would otherwise fall below fp16's normal range when staged."""
+        self.use_fp16 = True
+        if self.w is not None:
+            self._pack_f16()
         return self
+
+    def convert_to_fp32(self):
+        self.use_fp16 = False
+        return self
+
+    def _pack_f16(self):
+        for key, raw in self._raw.items():
+            if key + ".f16" not in self.w:
+                self.w[key + ".f16"] = ops.pack_conv_weight_f16(raw)
+
+    def _w16(self, key):
+        return self.w.get(key + ".f16") if self.use_fp16 else None
 
     def parameters(self):
         return iter(())
@@ -146,14 +167,21 @@ class EncoderUNetModel:
         dev = self.device
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
         w = {}
+        self._raw = {}
 
         def conv(name, raw, cin_pad=None):
             """forward weights and the data-gradient weights (input/output channels swapped, taps flipped)"""
             if raw.dim() == 3:
                 raw = raw.unsqueeze(-1)
             w[name + ".weight"] = ops.pack_conv_weight(raw, cin_pad=cin_pad)
-            w[name + ".dgrad"] = ops.pack_conv_weight(raw.permute(1, 0, 2, 3).flip(2, 3).contiguous())
+            rawT = raw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+            w[name + ".dgrad"] = ops.pack_conv_weight(rawT)
             w[name + ".bias"] = g(name + ".bias")
+            if raw.shape[2] == 3:           # candidates of the fp16-operand kernel (Cin % 64 == 0, Cout % 128 == 0)
+                if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
+                    self._raw[name + ".weight"] = raw
+                if rawT.shape[1] % 64 == 0 and rawT.shape[0] % 128 == 0:
+                    self._raw[name + ".dgrad"] = rawT
 
         for k in ("time_embed.0", "time_embed.2"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
@@ -187,6 +215,8 @@ class EncoderUNetModel:
         w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         self.w = w
         self._ws = None
+        if self.use_fp16:
+            self._pack_f16()
         return self
 
     # ------------------------------------------------------------------ forward (optionally recording a tape)
@@ -218,15 +248,18 @@ class EncoderUNetModel:
         if mode == "down":
             hp = ops.avgpool2_nhwc(x.t, gn=gn1, silu=True)
             xs = ops.avgpool2_nhwc(x.t)
-            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+            h = ops.conv2d(hp, w[n + ".in_layers.2.weight"], cout, 3, bias=w[n + ".in_layers.2.bias"], emit_stats=True,
+                           weight_f16=self._w16(n + ".in_layers.2.weight"))
         else:
             h = ops.conv2d(x, w[n + ".in_layers.2.weight"], cout, 3, gn=gn1, gn_silu=True,
-                           bias=w[n + ".in_layers.2.bias"], emit_stats=True)
+                           bias=w[n + ".in_layers.2.bias"], emit_stats=True,
+                           weight_f16=self._w16(n + ".in_layers.2.weight"))
             xs = x.t if cin == cout else ops.conv2d(x, w[n + ".skip_connection.weight"], cout, 1,
                                                     bias=w[n + ".skip_connection.bias"])
         gn2 = self._gn(h, n + ".out_layers.0", film=film_all[:, self._film_off[n]:], keep=k2)
         out = ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
-                         bias=w[n + ".out_layers.3.bias"], res=xs, emit_stats=True)
+                         bias=w[n + ".out_layers.3.bias"], res=xs, emit_stats=True,
+                         weight_f16=self._w16(n + ".out_layers.3.weight"))
         if tape is not None:
             tape.append(("res", n, L, x.t, h.t, k1, k2))
         return out
@@ -311,9 +344,9 @@ class EncoderUNetModel:
         _, n, L, x, h1, k1, k2 = rec
         w = self.w
         cin, cout, mode = L[1], L[2], L[3]
-        da2 = ops.conv2d(dout, w[n + ".out_layers.3.dgrad"], cout, 3)
+        da2 = ops.conv2d(dout, w[n + ".out_layers.3.dgrad"], cout, 3, weight_f16=self._w16(n + ".out_layers.3.dgrad"))
         dh1 = self._gn_bwd(h1, da2, k2, True)
-        da1 = ops.conv2d(dh1, w[n + ".in_layers.2.dgrad"], cin, 3)
+        da1 = ops.conv2d(dh1, w[n + ".in_layers.2.dgrad"], cin, 3, weight_f16=self._w16(n + ".in_layers.2.dgrad"))
         if mode == "down":
             return self._gn_bwd(x, da1, k1, True, add=dout, dA_ups=True, add_ups=True)
         skip = dout if cin == cout else ops.conv2d(dout, w[n + ".skip_connection.dgrad"], cin, 1)
@@ -358,6 +391,10 @@ class EncoderUNetModel:
         dlogits = torch.empty_like(logits)
         check(L.ddnm_logsoftmax_grad_f32(_p(logits), _p(yy), _p(dlogits), B, logits.shape[1], ops._stream()),
               "ddnm_logsoftmax_grad_f32")
+        gscale = GRAD_SCALE_FP16 if self.use_fp16 else 1.0
+        if gscale != 1.0:           # linear backward pass: evaluate on a scaled gradient, rescale at the end
+            check(L.ddnm_axpby_f32(_p(dlogits), None, _p(dlogits), dlogits.numel(), gscale, 0.0, ops._stream()),
+                  "ddnm_axpby_f32")
         # AttentionPool2d backward
         _, h_pre, kp, qkv, P = tape.pop()
         C, HW = self.final_ch, self.pool_sp ** 2
@@ -375,7 +412,11 @@ class EncoderUNetModel:
             rec = tape.pop()
             dh = self._res_bwd(rec, dh) if rec[0] == "res" else self._attn_bwd(rec, dh)
         n = "input_blocks.0.0"
-        return ops.conv2d(dh, w[n + ".dgrad"], self.in_channels, 3, out_nchw=True)
+        grad = ops.conv2d(dh, w[n + ".dgrad"], self.in_channels, 3, out_nchw=True)
+        if gscale != 1.0:
+            check(L.ddnm_axpby_f32(_p(grad), None, _p(grad), grad.numel(), 1.0 / gscale, 0.0, ops._stream()),
+                  "ddnm_axpby_f32")
+        return grad
 
 
 def make_cond_fn(classifier, classifier_scale):

@@ -182,7 +182,7 @@ class Diffusion(object):
             model = create_model(**vars(cfg.model))
             model.device = self.device
             if cfg.model.use_fp16:
-                model.convert_to_fp16()          # accepted; this build evaluates the ADM net in fp32
+                model.convert_to_fp16()          # 3x3 torso convolutions on fp16 MFMA operands (unet.py here)
             if cfg.model.class_cond:
                 ckpt = os.path.join(self.args.exp, "logs/imagenet/%dx%d_diffusion.pt" % (
                     cfg.data.image_size, cfg.data.image_size))

@@ -16,9 +16,10 @@ Kernel mapping (ddnm_amd/csrc), activations NHWC fp32 in HBM:
     (channel = head*192 + {q,k,v}*64 + c), QK^T and PV as batched MFMA GEMMs, fp32 softmax;
   * all `emb_layers` Linears -> ONE launch per step.
 
-Precision: this build evaluates the ADM net in fp32 on `v_mfma_f32_32x32x2_f32` (the reference's
-fp16 torso, fp16_util.py:15-22, is *less* precise); the fp16-storage MFMA variant is the next
-step for throughput.  `convert_to_fp16()` is accepted and ignored.
+Precision: fp32 on `v_mfma_f32_32x32x2_f32` by default; after `convert_to_fp16()` (what the runner calls for
+`use_fp16: true`, diffusion.py:145-146) the 3x3 convolutions of the torso run on fp16 MFMA operands with fp32
+accumulation (`v_mfma_f32_32x32x16_f16`, csrc/conv_igemm_f16.hip) while GroupNorm, softmax, embeddings and every
+tensor in HBM stay fp32 -- never less precise than the reference's fp16 torso (fp16_util.py:15-22).
 """
 import math
 from collections import OrderedDict

@@ -1,9 +1,3 @@
-cd /root/repo/ddnm_amd/csrc
-S="conv_igemm_f32.hip conv_igemm_f16.hip gemm_f32.hip groupnorm.hip misc.hip ddnm_step.hip fwht.hip backward.hip"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function -DDDNM_PROBE_NO_RES_FOLD $S -o /tmp/lib_nofold.so 2>/dev/null
-cp ../libddnm_hip.so /tmp/lib_fold.so
 cd /root/repo
-for v in fold nofold fold nofold fold nofold; do
-  cp /tmp/lib_$v.so ddnm_amd/libddnm_hip.so
-  echo -n "$v "; python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'])"
-done
+timeout 900 python -m pytest tests/test_classifier.py tests/test_gpu_cli.py -x -q -m gpu 2>&1 | tail -8
+python bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('c5', d['value'], d.get('ms_per_step'))"

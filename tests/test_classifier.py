@@ -73,6 +73,29 @@ def test_engine_classifier_logits_and_gradient(hip, kind, golden_dir):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mid", "full"])
+def test_engine_classifier_fp16_operands(hip, kind, golden_dir):
+    """`classifier.convert_to_fp16()` (imagenet_256_cc.yml: classifier_use_fp16 true): forward and data-gradient 3x3
+    convolutions on fp16 MFMA operands, everything else fp32; checked against the fp32 autograd goldens of the
+    reference at the half-precision bar of SURVEY.md section 8c."""
+    g = np.load(f"{golden_dir}/classifier.npz")
+    cc = weights.classifier_config(**KINDS[kind])
+    x, t, y = _inputs(cc.image_size)
+    m = _engine(cc, weights.classifier_state_dict(cc))
+    m.convert_to_fp16()
+    logits = m(x.cuda(), t.cuda())
+    torch.cuda.synchronize()
+    err = rel(logits, torch.from_numpy(g[f"{kind}_logits"]))
+    assert 1e-7 < err < 3e-3, err                    # > 1e-7: the fp16 kernels really ran
+    grad = m.log_prob_grad(x.cuda(), t.cuda(), y.cuda()).cpu()
+    ref = torch.from_numpy(g[f"{kind}_grad"])
+    got = grad if kind != "full" else grad[..., ::4, ::4]
+    assert rel(got, ref) < 1e-2, rel(got, ref)
+    cos = (got.double() * ref.double()).sum() / (got.double().norm() * ref.double().norm())
+    assert cos > 0.9999
+
+
+@pytest.mark.gpu
 def test_gn_backward_kernel(hip):
     """GroupNorm(+FiLM)+SiLU backward against torch autograd on CPU, incl. the half-resolution (avg-pool) mapping."""
     import torch.nn.functional as F
