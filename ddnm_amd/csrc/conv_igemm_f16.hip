@@ -72,7 +72,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
 
     uint4 h_st[HR];                                 // fp32 mode: 4 floats (bit-cast); fp16 mode: 8 halfs
-    uint4 b_st[BR];
+    // named registers, not an array: the compiler kept `uint4 b_st[BR]` in memory (promoted to a 16 KB LDS array),
+    // which turned every weight prefetch into load -> wait -> LDS -> barrier -> LDS -> LDS and exposed the full
+    // global-load latency once per tap
+    static_assert(BR == 2, "weight staging registers");
+    uint4 b_st0 = {0u, 0u, 0u, 0u}, b_st1 = {0u, 0u, 0u, 0u};
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
     const bool has_gn = !SRC16 && d.gn_scale != nullptr;
 
@@ -101,9 +105,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     auto prefetch_halo = [&](int chunk) { prefetch_halo_part(chunk, 0, HR); };
     auto prefetch_b = [&](int chunk, int tap) {
         const _Float16* wp = wbase + (size_t)tap * p.Cin + chunk * KC16;
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            b_st[i] = *reinterpret_cast<const uint4*>(wp + (size_t)(BROWS_PER_PASS * i) * 9 * p.Cin);
+        b_st0 = *reinterpret_cast<const uint4*>(wp);
+        b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin);
     };
     auto stage_halo_part = [&](int hbuf, int i0, int i1) {
 #pragma unroll
@@ -124,9 +127,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         }
     };
     auto stage_b = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<uint4*>(&Bs[buf * BN * LDH + (brow + BROWS_PER_PASS * i) * LDH + c8 * 8]) = b_st[i];
+        _Float16* dst = &Bs[buf * BN * LDH + brow * LDH + c8 * 8];
+        *reinterpret_cast<uint4*>(dst) = b_st0;
+        *reinterpret_cast<uint4*>(dst + BROWS_PER_PASS * LDH) = b_st1;
     };
 
     f32x16 acc[MT][NT];
@@ -192,6 +195,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                     if (tap == 3) { stage_halo_part(hb ^ 1, 0, HSPLIT); prefetch_halo_part(chunk + 1, HSPLIT, HR); }
                     if (tap == 6) stage_halo_part(hb ^ 1, HSPLIT, HR);
                 }
+#ifndef DDNM_PROBE16_NO_SCHED_BARRIER
+                // keep the global loads issued above in front of this tap's MFMAs: left alone, the scheduler sinks
+                // them behind the MFMAs (VGPR pressure) and their latency lands on the barrier of every tap
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 mfma_tap(tap, cur, hb);
 #ifndef DDNM_PROBE16_NO_TAP_BARRIER
                 __syncthreads();
@@ -232,9 +240,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
 #pragma unroll
             for (int i = 0; i < SR; ++i) s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)soff[i] * cs + coff + sc * 4);
-#pragma unroll
-            for (int i = 0; i < BR; ++i)
-                b_st[i] = *reinterpret_cast<const uint4*>(swbase + (size_t)(BROWS_PER_PASS * i) * SCin + cb);
+            b_st0 = *reinterpret_cast<const uint4*>(swbase + cb);
+            b_st1 = *reinterpret_cast<const uint4*>(swbase + (size_t)BROWS_PER_PASS * SCin + cb);
         };
         if (s_begin < s_end) prefetch_skip(s_begin);
         for (int ch = s_begin; ch < s_end; ++ch) {
