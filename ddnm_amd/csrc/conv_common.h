@@ -283,7 +283,8 @@ static __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(co
 static inline int splitk_stats_tiles(const ddnm_conv_desc* d) {
     const int hw = d->Ho * d->Wo;
     if (d->out_nchw || d->Cout % 4 || d->Cout > 1024 || hw % 4) return 0;
-    int tpi = hw / 4 < 32 ? hw / 4 : 32;
+    // enough workgroups to fill 256 CUs even at B = 1..4: <= 128 tiles per image, >= 4 pixels per tile
+    int tpi = hw / 4 < 128 ? hw / 4 : 128;
     while (tpi > 1 && hw % tpi) --tpi;
     return tpi;
 }
