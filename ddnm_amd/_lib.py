@@ -78,6 +78,10 @@ PROTOTYPES = {
     "ddnm_conv3x3_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv1x1_f16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv1x1_f16_supported": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv1x1_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
+    "ddnm_conv1x1_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_gn_stats_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                     c_int32, c_void_p]),
     "ddnm_gn_nchunk": (c_int32, [c_int32, c_int32]),

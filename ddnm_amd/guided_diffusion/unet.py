@@ -229,16 +229,22 @@ class UNetModel:
                     if L[1] != L[2]:
                         raw = g(n + ".skip_connection.weight")
                         w[n + ".skip_connection.weight"] = ops.pack_conv_weight(raw)
+                        if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
+                            self._raw[n + ".skip_connection.weight"] = raw
+                            self._f16_keys.append(n + ".skip_connection.weight")
                         w[n + ".skip_connection.bias"] = g(n + ".skip_connection.bias")
                         w[n + ".skip_connection.fused"] = ops.pack_skip_weight(raw)
                         w[n + ".skip_connection.fused.f16"] = ops.pack_skip_weight(raw, f16=True)
                         w[n + ".out_plus_skip.bias"] = (g(n + ".out_layers.3.bias") + g(n + ".skip_connection.bias")).contiguous()
                 else:
                     w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
-                    w[n + ".qkv.weight"] = ops.pack_conv_weight(g(n + ".qkv.weight").unsqueeze(-1))
-                    w[n + ".qkv.bias"] = g(n + ".qkv.bias")
-                    w[n + ".proj_out.weight"] = ops.pack_conv_weight(g(n + ".proj_out.weight").unsqueeze(-1))
-                    w[n + ".proj_out.bias"] = g(n + ".proj_out.bias")
+                    for conv in ("qkv", "proj_out"):                     # Conv1d(k=1) == 1x1 convolution
+                        raw = g(f"{n}.{conv}.weight").unsqueeze(-1)
+                        w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
+                        w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
+                        if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
+                            self._raw[f"{n}.{conv}.weight"] = raw
+                            self._f16_keys.append(f"{n}.{conv}.weight")
         w["film_cat.weight"] = torch.cat(fw, 0).contiguous()
         w["film_cat.bias"] = torch.cat(fb, 0).contiguous()
         w["out.0.weight"], w["out.0.bias"] = g("out.0.weight"), g("out.0.bias")
@@ -302,7 +308,7 @@ class UNetModel:
                                       skip_weight_f16=w[n + ".skip_connection.fused.f16"], emit_stats=True,
                                       weight_f16=self._w16(n + ".out_layers.3.weight"))
                 xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
-                                bias=w[n + ".skip_connection.bias"])
+                                bias=w[n + ".skip_connection.bias"], weight_f16=self._w16(n + ".skip_connection.weight"))
             else:
                 assert x1 is None
                 xs = x0
@@ -318,7 +324,8 @@ class UNetModel:
         hc = self.num_head_channels if self.num_head_channels != -1 else C // self.num_heads
         nh = C // hc
         gn = self._gn(x, None, n + ".norm")
-        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"],
+                         weight_f16=self._w16(n + ".qkv.weight"))
         flat = qkv.view(-1)
         S = torch.empty(B * nh, T, T, dtype=torch.float32, device=qkv.device)
         ops.bgemm(flat, flat[hc:], S, T, T, hc, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
@@ -327,7 +334,8 @@ class UNetModel:
         o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
         ops.bgemm(S, flat[2 * hc:], o, T, hc, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B * nh, inner=nh,
                   sA=(nh * T * T, T * T), sB=(T * 3 * C, 3 * hc), sC=(T * C, hc))
-        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True,
+                          weight_f16=self._w16(n + ".proj_out.weight"))
 
     def _run(self, prefix, layers, h, skip, film_all):
         for j, L in enumerate(layers):

@@ -159,11 +159,19 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     L = _lib.lib()
     # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
     # shape qualifies; everything else runs the exact-fp32 kernels
-    f16 = weight_f16 is not None and L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
+    f16, f16_1x1 = False, False
+    if weight_f16 is not None:
+        if ksize == 3:
+            f16 = L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
+        elif ksize == 1 and skip is None:
+            d.gn_scale, d.gn_shift = None, None         # the GEMM kernel has no fused prologue: always the pre-pass
+            f16 = f16_1x1 = L.ddnm_conv1x1_f16_supported(ctypes.byref(d)) == 1
+            if not f16 and gn is not None:
+                d.gn_scale, d.gn_shift = _p(gn[0]), _p(gn[1])
     if f16:
         d.weight = weight_f16.data_ptr()
-        if gn is not None and cout >= _F16_PREPASS_MIN_COUT:
-            # GroupNorm + swish once per element into an fp16 scratch tensor instead of once per
+        if gn is not None and (f16_1x1 or cout >= _F16_PREPASS_MIN_COUT):
+            # GroupNorm (+ swish) once per element into an fp16 scratch tensor instead of once per
             # (128-output-channel tile x halo overlap) inside the conv's loader
             h16 = _f16_scratch(src0.device, B * Hs * Ws * (C0 + C1))
             check(L.ddnm_gn_apply_f16(_p(src0), _p(src1), _p(gn[0]), _p(gn[1]), h16.data_ptr(), B, Hs * Ws, C0, C1,
@@ -179,9 +187,12 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         d.skip_weight = _p(skip_weight_f16) if f16 else _p(skip_weight)
         if f16 and skip_weight_f16 is None:
             raise ValueError("fp16 launch with a fused shortcut needs skip_weight_f16")
-    fn_run = L.ddnm_conv3x3_f16_f32 if f16 else L.ddnm_conv2d_f32
-    fn_tiles = L.ddnm_conv3x3_f16_stats_tiles if f16 else L.ddnm_conv2d_f32_stats_tiles
-    fn_ws = L.ddnm_conv3x3_f16_workspace_floats if f16 else L.ddnm_conv2d_f32_workspace_floats
+    if f16_1x1:
+        fn_run, fn_tiles, fn_ws = L.ddnm_conv1x1_f16_f32, L.ddnm_conv1x1_f16_stats_tiles, L.ddnm_conv1x1_f16_workspace_floats
+    elif f16:
+        fn_run, fn_tiles, fn_ws = L.ddnm_conv3x3_f16_f32, L.ddnm_conv3x3_f16_stats_tiles, L.ddnm_conv3x3_f16_workspace_floats
+    else:
+        fn_run, fn_tiles, fn_ws = L.ddnm_conv2d_f32, L.ddnm_conv2d_f32_stats_tiles, L.ddnm_conv2d_f32_workspace_floats
     stats, tiles = None, 0
     if emit_stats and not _NO_FUSED_GN:
         tiles = fn_tiles(ctypes.byref(d))
@@ -195,7 +206,9 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     if _timer is None:
         check(fn_run(ctypes.byref(d), _stream()), "ddnm_conv2d")
     else:
-        if f16:
+        if f16_1x1:
+            variant = "conv1x1_f16<256x128>"
+        elif f16:
             variant = "conv3x3_halo_f16<256x128>"
         else:
             tn = L.ddnm_conv2d_f32_tile_n(ctypes.byref(d))

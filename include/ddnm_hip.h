@@ -106,6 +106,16 @@ int ddnm_conv3x3_f16_supported(const ddnm_conv_desc* d);
 int64_t ddnm_conv3x3_f16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d);
 
+/* 1x1 convolution with fp16 MFMA operands, fp32 accumulate / output: the attention blocks' qkv and proj_out
+ * Conv1d(k=1) and un-fused 1x1 shortcuts of the `use_fp16` torso (guided_diffusion/unet.py:222,283-289,301-308).
+ * Same descriptor with ksize = 1, stride 1, pad 0; `weight` = (O,1,I)-packed fp16; src fp32, or fp16 with src_f16 = 1
+ * (output of ddnm_gn_apply_f16 -- there is no fused GroupNorm prologue: gn_scale must be NULL).  Needs Cin % 64 == 0,
+ * Cout % 128 == 0, B*Ho*Wo % 256 == 0; statistics only when Ho*Wo % 256 == 0. */
+int ddnm_conv1x1_f16_f32(const ddnm_conv_desc* d, void* stream);
+int ddnm_conv1x1_f16_supported(const ddnm_conv_desc* d);
+int64_t ddnm_conv1x1_f16_workspace_floats(const ddnm_conv_desc* d);
+int ddnm_conv1x1_f16_stats_tiles(const ddnm_conv_desc* d);
+
 /* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
  * Replaces torch.nn.GroupNorm(32, C, eps) (models.py:32-33; guided_diffusion/nn.py:17-19).

@@ -131,6 +131,48 @@ def test_conv3x3_f16_operands(hip, B, C0, C1, Cout, H, gn, res, ups):
     assert rel(got, ref32) < 2e-3
 
 
+@pytest.mark.parametrize("B,C0,C1,Cout,H,gn,res", [(4, 512, 0, 1536, 32, True, False),     # qkv of a 32x32 attention block
+                                                   (4, 1024, 0, 1024, 16, False, True),    # proj_out + residual
+                                                   (4, 1024, 0, 3072, 8, True, False),     # 8x8 level: batch folded, split-K
+                                                   (2, 512, 256, 256, 32, False, False),   # un-fused shortcut over a concat
+                                                   (1, 256, 0, 768, 16, True, False)])
+def test_conv1x1_f16_operands(hip, B, C0, C1, Cout, H, gn, res):
+    """1x1 convolutions of the fp16 torso (qkv / proj_out / shortcut) on the fp16 GEMM kernel: against an fp32
+    convolution of the fp16-rounded operands (2e-5) and of the unrounded ones (fp16-class, 2e-3); the emitted
+    GroupNorm partials reproduce F.group_norm of the output."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(13)
+    Cin = C0 + C1
+    a = torch.randn(B, C0, H, H, generator=g)
+    b = torch.randn(B, C1, H, H, generator=g) if C1 else None
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * Cin ** -0.5
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.randn(B, Cin, generator=g), torch.randn(B, Cin, generator=g)
+    r = torch.randn(B, Cout, H, H, generator=g) if res else None
+    x = a if b is None else torch.cat([a, b], 1)
+    act = x * sc[:, :, None, None] + sh[:, :, None, None] if gn else x
+    ref32 = F.conv2d(act, w, bias) + (r if res else 0)
+    ref16 = F.conv2d(act.half().float(), w.half().float(), bias) + (r if res else 0)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()       # noqa: E731
+    out = ops.conv2d(nh(a), ops.pack_conv_weight(w.cuda()), Cout, 1, src1=None if b is None else nh(b), bias=bias.cuda(),
+                     gn=(sc.cuda().contiguous(), sh.cuda().contiguous()) if gn else None, gn_silu=False,
+                     res=nh(r) if res else None, emit_stats=True, weight_f16=ops.pack_conv_weight_f16(w.cuda()))
+    torch.cuda.synchronize()
+    got = out.t.cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref16) < 2e-5
+    assert rel(got, ref32) < 2e-3
+    if out.stats is not None:
+        gamma, beta = torch.ones(Cout), torch.zeros(Cout)
+        ws = ops.GroupNormWorkspace("cuda", B, Cout, 16)
+        s2, h2 = ops.group_norm_affine(out, None, gamma.cuda(), beta.cuda(), 1e-5, ws)
+        torch.cuda.synchronize()
+        s2, h2 = s2[:B * Cout].reshape(B, Cout).cpu(), h2[:B * Cout].reshape(B, Cout).cpu()
+        assert rel(got * s2[:, :, None, None] + h2[:, :, None, None], F.group_norm(got, 32, eps=1e-5)) < 1e-5
+    else:
+        assert H * H % 256 != 0
+
+
 @pytest.mark.parametrize("C0,C1,Cout,H,ups", [(256, 0, 256, 32, False), (256, 256, 256, 32, False), (128, 0, 512, 16, True)])
 def test_conv3x3_f16_groupnorm_prepass_is_bit_identical(hip, monkeypatch, C0, C1, Cout, H, ups):
     """ddnm_gn_apply_f16 + conv(src_f16) == the fused GroupNorm/swish prologue, bit for bit (same fp32 math,
