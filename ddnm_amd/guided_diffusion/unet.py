@@ -30,6 +30,7 @@ from .. import ops
 
 GN_EPS = 1e-5          # torch.nn.GroupNorm default, guided_diffusion/nn.py:93-100
 CIN_PAD = 32
+CIN_PAD_F16 = 64        # one K chunk of the fp16-operand kernel
 NUM_CLASSES = 1000
 
 
@@ -149,6 +150,9 @@ class UNetModel:
         for key in self._f16_keys:
             if key + ".f16" not in self.w:
                 self.w[key + ".f16"] = ops.pack_conv_weight_f16(self._raw[key])
+        for key, raw in self._raw.items():
+            if key.endswith(".pad64") and key + ".f16" not in self.w:
+                self.w[key + ".f16"] = ops.pack_conv_weight_f16(raw, cin_pad=CIN_PAD_F16)
 
     def parameters(self):
         return iter(())
@@ -214,6 +218,8 @@ class UNetModel:
                 if L[0] == "conv":
                     w[n + ".weight"] = ops.pack_conv_weight(g(n + ".weight"), cin_pad=CIN_PAD)
                     w[n + ".bias"] = g(n + ".bias")
+                    if L[2] % 128 == 0:          # fp16 mode: the 3 input channels are zero-padded to one 64-channel chunk
+                        self._raw[n + ".weight.pad64"] = g(n + ".weight")
                 elif L[0] == "res":
                     for norm in ("in_layers.0", "out_layers.0"):
                         w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
@@ -365,9 +371,22 @@ class UNetModel:
             ops.embedding_add_(emb, w["label_emb.weight"], y)
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
 
-        h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD)
+        n0 = "input_blocks.0.0"
+        H, W = x.shape[2], x.shape[3]
+        if self.use_fp16 and n0 + ".weight.pad64.f16" in w and ops.conv_runs_f16(B, H, W, CIN_PAD_F16, self.input_blocks[0][0][2]):
+            # the input convolution belongs to the fp16 torso too (unet.py:619-625)
+            h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD_F16)
+            h = ops.conv2d(h, w[n0 + ".weight"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"], emit_stats=True,
+                           weight_f16=w[n0 + ".weight.pad64.f16"])
+            first = 1
+        else:
+            h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD)
+            first = 0
         hs = []
         for i, layers in enumerate(self.input_blocks):
+            if i == 0 and first:
+                hs.append(h)
+                continue
             h = self._run(f"input_blocks.{i}", layers, h, None, film_all)
             hs.append(h)
         h = self._run("middle_block", self.middle_block, h, None, film_all)

@@ -109,9 +109,18 @@ def pack_skip_weight(w, f16=False):
     return p.to(torch.float16) if f16 else p
 
 
-def pack_conv_weight_f16(w):
+def pack_conv_weight_f16(w, cin_pad=None):
     """OIHW fp32/fp16 -> (O, ky, kx, I) IEEE fp16, Cout padded to 128 (operands of ddnm_conv3x3_f16_f32)."""
-    return pack_conv_weight(w).to(torch.float16).contiguous()
+    return pack_conv_weight(w, cin_pad=cin_pad).to(torch.float16).contiguous()
+
+
+def conv_runs_f16(B, H, W, cin, cout, ksize=3):
+    """True when a stride-1 conv of this shape takes the fp16-operand kernel (given packed fp16 weights)."""
+    d = ConvDesc()
+    d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, H, W, cin, 0, cout
+    d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, 1, ksize // 2, H, W
+    L = _lib.lib()
+    return (L.ddnm_conv3x3_f16_supported if ksize == 3 else L.ddnm_conv1x1_f16_supported)(ctypes.byref(d)) == 1
 
 
 _F16_PREPASS_MIN_COUT = int(_os.environ.get("DDNM_F16_PREPASS_MIN_COUT", "256"))
