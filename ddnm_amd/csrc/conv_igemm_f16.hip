@@ -75,8 +75,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     // named registers, not an array: the compiler kept `uint4 b_st[BR]` in memory (promoted to a 16 KB LDS array),
     // which turned every weight prefetch into load -> wait -> LDS -> barrier -> LDS -> LDS and exposed the full
     // global-load latency once per tap
-    static_assert(BR == 2, "weight staging registers");
-    uint4 b_st0 = {0u, 0u, 0u, 0u}, b_st1 = {0u, 0u, 0u, 0u};
+    static_assert(BR == 2 || BR == 4, "weight staging registers");
+    uint4 b_st0 = {0u, 0u, 0u, 0u}, b_st1 = {0u, 0u, 0u, 0u}, b_st2 = {0u, 0u, 0u, 0u}, b_st3 = {0u, 0u, 0u, 0u};
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
     const bool has_gn = !SRC16 && d.gn_scale != nullptr;
 
@@ -105,8 +105,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     auto prefetch_halo = [&](int chunk) { prefetch_halo_part(chunk, 0, HR); };
     auto prefetch_b = [&](int chunk, int tap) {
         const _Float16* wp = wbase + (size_t)tap * p.Cin + chunk * KC16;
+#ifdef DDNM_PROBE16_NO_BLOAD
+        if (chunk < 0) {
+#endif
         b_st0 = *reinterpret_cast<const uint4*>(wp);
         b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin);
+        if constexpr (BR == 4) {
+            b_st2 = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * BROWS_PER_PASS) * 9 * p.Cin);
+            b_st3 = *reinterpret_cast<const uint4*>(wp + (size_t)(3 * BROWS_PER_PASS) * 9 * p.Cin);
+        }
+#ifdef DDNM_PROBE16_NO_BLOAD
+        }
+#endif
     };
     auto stage_halo_part = [&](int hbuf, int i0, int i1) {
 #pragma unroll
@@ -130,6 +140,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         _Float16* dst = &Bs[buf * BN * LDH + brow * LDH + c8 * 8];
         *reinterpret_cast<uint4*>(dst) = b_st0;
         *reinterpret_cast<uint4*>(dst + BROWS_PER_PASS * LDH) = b_st1;
+        if constexpr (BR == 4) {
+            *reinterpret_cast<uint4*>(dst + 2 * BROWS_PER_PASS * LDH) = b_st2;
+            *reinterpret_cast<uint4*>(dst + 3 * BROWS_PER_PASS * LDH) = b_st3;
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -242,6 +256,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             for (int i = 0; i < SR; ++i) s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)soff[i] * cs + coff + sc * 4);
             b_st0 = *reinterpret_cast<const uint4*>(swbase + cb);
             b_st1 = *reinterpret_cast<const uint4*>(swbase + (size_t)BROWS_PER_PASS * SCin + cb);
+            if constexpr (BR == 4) {
+                b_st2 = *reinterpret_cast<const uint4*>(swbase + (size_t)(2 * BROWS_PER_PASS) * SCin + cb);
+                b_st3 = *reinterpret_cast<const uint4*>(swbase + (size_t)(3 * BROWS_PER_PASS) * SCin + cb);
+            }
         };
         if (s_begin < s_end) prefetch_skip(s_begin);
         for (int ch = s_begin; ch < s_end; ++ch) {
@@ -343,11 +361,14 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     p.ksplit = pl.ksplit;
     p.ws = d->workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (d->src_f16) {
-        DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
-    } else {
-        DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), dim3(p.m_tiles * p.n_tiles, pl.ksplit), dim3(512), 0, s, p);
-    }
+    const dim3 grid(p.m_tiles * p.n_tiles, pl.ksplit);
+#ifdef DDNM_F16_WAVE128        // probe: 4 waves with 128x64 wave tiles (25 % fewer LDS fragment reads per MFMA)
+    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
+    else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
+#else
+    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
+    else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), grid, dim3(512), 0, s, p); }
+#endif
     if (pl.ksplit > 1) return launch_splitk_reduce(p, s);
     return 0;
 }

@@ -29,21 +29,21 @@ if HERE not in sys.path:
 
 FLAGS = [
     # (names, kwargs) in the order of the reference parser
-    (("--config",), dict(type=str, required=True, help="Path to the config file")),
-    (("--seed",), dict(type=int, default=1234, help="Set different seeds for diverse results")),
-    (("--exp",), dict(type=str, default="exp", help="Path for saving running related data.")),
-    (("--deg",), dict(type=str, required=True, help="Degradation")),
-    (("--path_y",), dict(type=str, required=True, help="Path of the test dataset.")),
-    (("--sigma_y",), dict(type=float, default=0.0, help="sigma_y")),
-    (("--eta",), dict(type=float, default=0.85, help="Eta")),
-    (("--simplified",), dict(action="store_true", help="Use simplified DDNM, without SVD")),
-    (("-i", "--image_folder"), dict(type=str, default="images", help="The folder name of samples")),
-    (("--deg_scale",), dict(type=float, default=0.0, help="deg_scale")),
-    (("--verbose",), dict(type=str, default="info", help="Verbose level: info | debug | warning | critical")),
-    (("--ni",), dict(action="store_true", help="No interaction. Suitable for Slurm Job launcher")),
+    (("--config",), dict(type=str, required=True, help="YAML under configs/ (or an absolute path)")),
+    (("--seed",), dict(type=int, default=1234, help="seed of torch / numpy / the device generator")),
+    (("--exp",), dict(type=str, default="exp", help="root of the run directory (<exp>/image_samples, <exp>/datasets, <exp>/logs)")),
+    (("--deg",), dict(type=str, required=True, help="degradation operator, e.g. sr_bicubic, colorization, inpainting, cs_walshhadamard, deblur_gauss")),
+    (("--path_y",), dict(type=str, required=True, help="dataset sub-folder below <exp>/datasets, or synthetic:N")),
+    (("--sigma_y",), dict(type=float, default=0.0, help="std of the measurement noise on the [0,1] scale (> 0 selects DDNM+)")),
+    (("--eta",), dict(type=float, default=0.85, help="eta of the DDIM-style update")),
+    (("--simplified",), dict(action="store_true", help="inlined A / A^+ loop of the reference (batch size 1)")),
+    (("-i", "--image_folder"), dict(type=str, default="images", help="output folder below <exp>/image_samples")),
+    (("--deg_scale",), dict(type=float, default=0.0, help="operator parameter: SR factor, CS ratio, ...")),
+    (("--verbose",), dict(type=str, default="info", help="logging level name")),
+    (("--ni",), dict(action="store_true", help="never prompt: an existing output folder is replaced")),
     (("--subset_start",), dict(type=int, default=-1)),
     (("--subset_end",), dict(type=int, default=-1)),
-    (("-n", "--noise_type"), dict(type=str, default="gaussian", help="gaussian | 3d_gaussian | poisson | speckle")),
+    (("-n", "--noise_type"), dict(type=str, default="gaussian", help="accepted for compatibility (unused, like in the reference)")),
     (("--add_noise",), dict(action="store_true")),
 ]
 
