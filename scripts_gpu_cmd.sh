@@ -1,3 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_gpu_adm.py -x -q -m gpu 2>&1 | tail -5
-python tools/adm_probe.py 2>&1 | grep "fp16:" -A6
+for w in c3 c4 c5; do
+  python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_$w.json
+  python -c "import json; d=json.load(open('gpurun_out/bench_$w.json')); print('$w', d['value'], d['ms_per_step'], d['config'].get('whole_loop_tflops_per_gpu'))"
+done
