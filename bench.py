@@ -281,6 +281,14 @@ def main():
         summ = timer.summary()
         dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
         name, r = dom
+        # algorithmic HBM bytes of the same launches: every operand once (input [+ shortcut input] + weights +
+        # output [+ residual]), fp32 -- what `traffic` (PMC) is to be compared with
+        alg = []
+        for (variant, _, _, _), (b_, ho, wo, cin, cout, k, stride, ups, skipc, _, has_res) in zip(timer.records, timer.shapes):
+            if variant == name:
+                pix_in = b_ * ho * wo * stride * stride // (4 if ups else 1)
+                alg.append(4.0 * (pix_in * cin + b_ * ho * wo * skipc + cout * (k * k * cin + skipc)
+                                  + b_ * ho * wo * cout * (2 if has_res else 1)))
         total_ms = sum(v["ms"] for v in summ.values())
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         # HBM traffic / MFMA-busy of the same kernel come from separate rocprofv3 --pmc passes (bench.py cannot
@@ -294,6 +302,7 @@ def main():
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
             "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_dominant_kernel.json",
+            "traffic_algorithmic": round(sum(alg) / max(1, len(alg)), 1),
             "mfma_busy_pmc": mfma_busy,
             "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
             "avg_flops_per_launch": r["flops"] / r["launches"],

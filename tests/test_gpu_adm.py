@@ -208,3 +208,29 @@ def test_adm_forward_fp16_torso(hip, kind, batch, golden_dir):
     got = e if kind != "full" else e[..., ::4, ::4]
     err = rel(got, ref)
     assert 1e-7 < err < 3e-3, err            # > 1e-7: the fp16 path really ran
+
+
+@pytest.mark.parametrize("name", ["colorization", "inpainting"])
+def test_adm_sampler_fp16_torso_psnr_bar(hip, name, golden_dir):
+    """The same 56-iteration time-travel run with `convert_to_fp16()`: against the reference's fp32 golden the
+    restored images agree to the bar of SURVEY.md section 8c -- |PSNR(engine, x_orig) - PSNR(reference, x_orig)|
+    <= 0.1 dB -- and image-to-image PSNR is high (the loop is not chaotic under fp16-class perturbations)."""
+    from ddnm_amd.functions.svd_ddnm import ddnm_diffusion
+    from oracle import cases, sampler, schedule
+    cfg, sd = cases.adm_net("mid")
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 20, 2, 2
+    n_it = len(schedule.jump_times(20, 2, 2)) - 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 2, n_it)
+    y = cases.make_operator(name, cfg.data.image_size).A(x_orig)
+    op = engine_operator(name, cfg.data.image_size)
+    m = build(cfg, sd)
+    m.convert_to_fp16()
+    xs, _ = ddnm_diffusion(x_T.cuda(), m, cases.betas().cuda(), 0.85, op, y.cuda(), cls_fn=None, classes=None,
+                           config=cfg, noise=[n.cuda() for n in tape])
+    torch.cuda.synchronize()
+    got = xs[0].cpu()
+    ref = torch.from_numpy(np.load(f"{golden_dir}/adm_forward.npz")[f"mid_{name}_x"])
+    err = rel(got, ref)
+    assert 1e-7 < err < 2e-2, err
+    assert (sampler.psnr(got, x_orig) - sampler.psnr(ref, x_orig)).abs().max().item() <= 0.1
+    assert sampler.psnr(got, ref).min().item() > 35.0
