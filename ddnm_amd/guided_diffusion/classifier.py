@@ -12,7 +12,6 @@ backward is four batched MFMA GEMMs + `softmax_bwd_rows`, AttentionPool2d has it
 (csrc/backward.hip).  Weight gradients are never formed.  The state-dict (249 tensors, reference names,
 e.g. the public 256x256_classifier.pt) loads unchanged.
 """
-import ctypes
 import math
 from collections import OrderedDict
 
@@ -421,7 +420,6 @@ class EncoderUNetModel:
 
 def make_cond_fn(classifier, classifier_scale):
     """The `cond_fn` closure of guided_diffusion/diffusion.py:183-189 on the HIP engine."""
-    from .. import ops as _ops
 
     def cond_fn(x, t, y):
         g = classifier.log_prob_grad(x, t, y)

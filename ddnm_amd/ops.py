@@ -5,7 +5,6 @@ stream; every computation below is a hand-written HIP kernel from
 ddnm_amd/csrc.  Nothing in this module falls back to torch ops.
 """
 import ctypes
-import math
 
 import torch
 

@@ -1,9 +1,7 @@
 """The drop-in shell on the GPU: reference command lines through main.py / Diffusion, and the
 simplified (--simplified) loop against its oracle restatement."""
 import os
-import types
 
-import numpy as np
 import pytest
 import torch
 

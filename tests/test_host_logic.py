@@ -1,7 +1,6 @@
 """CPU tests of the host-side logic that needs no kernel launch."""
 import json
 import os
-import types
 
 import numpy as np
 import pytest
