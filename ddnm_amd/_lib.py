@@ -69,6 +69,8 @@ PROTOTYPES = {
     "ddnm_hq_sample_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                      c_float, c_void_p]),
     "ddnm_patchify_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_im2col3x3_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_void_p]),
     "ddnm_gn_apply_f16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, c_void_p]),
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,

@@ -142,7 +142,7 @@ static bool plan_1x1(const ddnm_conv_desc* d, Plan1x1* pl) {
     if (tiles < 128) {
         ks = (int)((256 + tiles - 1) / tiles);
         if (ks > nchunks / 2) ks = nchunks / 2;
-        if (ks > 8) ks = 8;
+        if (ks > 32) ks = 32;            // K = 9*C of an im2col'd 8x8 layer: up to 288 chunks
         if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;

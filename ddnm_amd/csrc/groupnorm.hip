@@ -259,3 +259,57 @@ extern "C" int ddnm_gn_apply_f16(const float* src0, const float* src1, const flo
                 reinterpret_cast<_Float16*>(out_f16), HW, C0, C1, silu, total8);
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// im2col of a 3x3 / stride 1 / pad 1 convolution input with the GroupNorm affine (+ swish) prologue, fp16 output:
+// col[(b*HW + p)][tap*C + c] = act(concat_c(src0, src1)[b, y+ky-1, x+kx-1, c]) (0 outside the image).
+// Only for the lowest-resolution level of the fp16 torso (8x8: 64 pixels per image): a 256-pixel MFMA tile would
+// span four images, so the layer runs as ONE GEMM over [B*64][9*C] on conv1x1_f16_kernel instead (the column matrix
+// is a few MB).  Thread = 8 consecutive channels of one (pixel, tap).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col3x3_f16_kernel(const float* __restrict__ src0, const float* __restrict__ src1,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            _Float16* __restrict__ out, int H, int W, int C0, int C1,
+                                                            int silu, size_t total8) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int C = C0 + C1, C8 = C >> 3, HW = H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        size_t t = i / C8;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int p = (int)(t % HW), b = (int)(t / HW);
+        const int y = p / W + tap / 3 - 1, x = p % W + tap % 3 - 1;
+        half8 h = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const size_t pix = (size_t)b * HW + (size_t)y * W + x;
+            const float* s = c < C0 ? src0 + pix * C0 + c : src1 + pix * C1 + (c - C0);
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(s), v1 = *reinterpret_cast<const f32x4*>(s + 4);
+            if (scale) {
+                const float* sc = scale + (size_t)b * C + c;
+                const float* sh = shift + (size_t)b * C + c;
+                v0 = gn_act(v0, *reinterpret_cast<const f32x4*>(sc), *reinterpret_cast<const f32x4*>(sh), silu);
+                v1 = gn_act(v1, *reinterpret_cast<const f32x4*>(sc + 4), *reinterpret_cast<const f32x4*>(sh + 4), silu);
+            }
+            h = half8{(_Float16)v0.x, (_Float16)v0.y, (_Float16)v0.z, (_Float16)v0.w,
+                      (_Float16)v1.x, (_Float16)v1.y, (_Float16)v1.z, (_Float16)v1.w};
+        }
+        *reinterpret_cast<half8*>(out + i * 8) = h;
+    }
+}
+
+extern "C" int ddnm_im2col3x3_f16(const float* src0, const float* src1, const float* scale, const float* shift,
+                                  void* out_f16, int32_t B, int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t silu,
+                                  void* stream) {
+    if (!src0 || !out_f16 || B <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0) return DDNM_E_BADARG;
+    if ((scale == nullptr) != (shift == nullptr)) return DDNM_E_BADARG;
+    if ((C0 | C1) & 7) return DDNM_E_SHAPE;
+    if (C1 > 0 && !src1) return DDNM_E_BADARG;
+    const size_t total8 = (size_t)B * H * W * 9 * (C0 + C1) / 8;
+    const size_t blocks = (total8 + 255) / 256;
+    const unsigned g = (unsigned)(blocks < 16384 ? blocks : 16384);
+    DDNM_LAUNCH(im2col3x3_f16_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src0, src1, scale, shift,
+                reinterpret_cast<_Float16*>(out_f16), H, W, C0, C1, silu, total8);
+    return 0;
+}

@@ -306,7 +306,8 @@ class UNetModel:
             res_ups = False
             if cin != cout:
                 B, H, W, _ = h.t.shape
-                if ops.conv_fuses_skip(B, H, W, cout, cout):       # shortcut fused into out_layers.3 as extra K
+                lowres_f16 = self.use_fp16 and H * W < 256        # runs as im2col + fp16 GEMM: shortcut stays a GEMM
+                if ops.conv_fuses_skip(B, H, W, cout, cout) and not lowres_f16:   # shortcut fused into out_layers.3 as extra K
                     gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
                     return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
                                       bias=w[n + ".out_plus_skip.bias"], skip=(x0, x1),

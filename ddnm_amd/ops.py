@@ -126,12 +126,13 @@ _F16_PREPASS_MIN_COUT = int(_os.environ.get("DDNM_F16_PREPASS_MIN_COUT", "256"))
 _f16_scratch_buf = {}
 
 
-def _f16_scratch(device, numel):
-    """fp16 activation scratch of the GroupNorm pre-pass (stream order makes reuse safe)."""
-    buf = _f16_scratch_buf.get(device)
+def _f16_scratch(device, numel, slot=0):
+    """fp16 activation scratch of the GroupNorm pre-pass (slot 0) / the im2col matrix (slot 1); stream order makes
+    reuse safe."""
+    buf = _f16_scratch_buf.get((device, slot))
     if buf is None or buf.numel() < numel:
         buf = torch.empty(numel, dtype=torch.float16, device=device)
-        _f16_scratch_buf[device] = buf
+        _f16_scratch_buf[(device, slot)] = buf
     return buf
 
 
@@ -171,6 +172,22 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     if weight_f16 is not None:
         if ksize == 3:
             f16 = L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
+            if (not f16 and stride == 1 and not ups and skip is None and not out_nchw and not res_ups
+                    and Hs * Ws < 256 and (C0 | C1) % 8 == 0):
+                # lowest-resolution level (a 256-pixel tile would span several images): im2col with the GroupNorm
+                # prologue, then ONE fp16 GEMM with K = 9*Cin -- the (O,ky,kx,I)-packed weights are its matrix
+                d.ksize, d.pad, d.C0, d.C1, d.gn_scale, d.gn_shift = 1, 0, 9 * (C0 + C1), 0, None, None
+                if L.ddnm_conv1x1_f16_supported(ctypes.byref(d)) == 1:
+                    col = _f16_scratch(src0.device, B * Hs * Ws * 9 * (C0 + C1), slot=1)
+                    check(L.ddnm_im2col3x3_f16(_p(src0), _p(src1), None if gn is None else _p(gn[0]),
+                                               None if gn is None else _p(gn[1]), col.data_ptr(), B, Hs, Ws, C0, C1,
+                                               int(gn_silu), _stream()), "ddnm_im2col3x3_f16")
+                    d.src0, d.src1, d.src_f16 = col.data_ptr(), None, 1
+                    f16 = f16_1x1 = True
+                    gn = None
+                else:
+                    d.ksize, d.pad, d.C0, d.C1 = 3, pad, C0, C1
+                    d.gn_scale, d.gn_shift = (None, None) if gn is None else (_p(gn[0]), _p(gn[1]))
         elif ksize == 1 and skip is None:
             d.gn_scale, d.gn_shift = None, None         # the GEMM kernel has no fused prologue: always the pre-pass
             f16 = f16_1x1 = L.ddnm_conv1x1_f16_supported(ctypes.byref(d)) == 1

@@ -141,6 +141,12 @@ int ddnm_gn_finalize_f32(const double* partial, int32_t nchunk, const float* gam
  * which repeats the v_exp / v_rcp work once per 128-output-channel tile. */
 int ddnm_gn_apply_f16(const float* src0, const float* src1, const float* scale, const float* shift, void* out_f16,
                       int32_t B, int32_t HW, int32_t C0, int32_t C1, int32_t silu, void* stream);
+/* im2col of a 3x3 / stride 1 / pad 1 input with the GroupNorm affine (+ swish) prologue, fp16 output
+ * col[B*H*W][9*(C0+C1)] (column = tap*C + c, zero outside the image); scale / shift may both be NULL.
+ * The 8x8 level of the fp16 torso then runs as one ddnm_conv1x1_f16_f32 GEMM with K = 9*C (the (O,ky,kx,I)-packed
+ * 3x3 weights ARE the [Cout][9*C] matrix).  C0 % 8 == 0, C1 % 8 == 0. */
+int ddnm_im2col3x3_f16(const float* src0, const float* src1, const float* scale, const float* shift, void* out_f16,
+                       int32_t B, int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t silu, void* stream);
 int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tiles_per_img0, int32_t C0, const float* part1,
                                int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
                                int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,

@@ -96,7 +96,10 @@ def test_adm_sampler_vs_reference_golden(hip, name, golden_dir):
                                                        (2, 256, 256, 256, 16, True, False, False),
                                                        (1, 128, 0, 128, 64, False, True, False),
                                                        (1, 256, 0, 256, 16, True, True, True),
-                                                       (4, 512, 0, 512, 16, True, True, False)])
+                                                       (4, 512, 0, 512, 16, True, True, False),
+                                                       (4, 1024, 0, 1024, 8, True, True, False),     # 8x8: im2col + fp16 GEMM
+                                                       (4, 512, 512, 512, 8, True, False, False),    # ... over a concat
+                                                       (4, 256, 0, 256, 8, False, True, False)])     # ... without GroupNorm
 def test_conv3x3_f16_operands(hip, B, C0, C1, Cout, H, gn, res, ups):
     """fp16 MFMA operands, fp32 accumulate.  Checked two ways: (a) against an fp32 convolution of the
     fp16-ROUNDED operands (isolates the kernel: only accumulation order differs, tol 2e-5), (b) against
