@@ -33,7 +33,17 @@ def build(force=False, verbose=False):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:       # one builder at a time (torchrun ranks)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+            return LIB
+        return _build_locked(dig, verbose)
+
+
+def _build_locked(dig, verbose):
+    tmp = LIB + f".tmp{os.getpid()}"          # link next to the target, then rename: never a half-written library
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -42,6 +52,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed")
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
+    os.replace(tmp, LIB)
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB
