@@ -165,6 +165,9 @@ def lib():
         except RuntimeError as e:
             if "hipcc not found" not in str(e):
                 raise
+        except OSError as e:                 # read-only tree, no lock file ...: use the binary that is there
+            import warnings
+            warnings.warn(f"ddnm_amd: could not check / rebuild libddnm_hip.so ({e}); loading the existing binary")
         if not os.path.exists(LIB_PATH):
             raise DDNMHipError(
                 f"{LIB_PATH} is missing: build it with `python -m ddnm_amd.build` "
