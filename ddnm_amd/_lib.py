@@ -157,17 +157,6 @@ def lib():
     """The loaded shared library; raises if it has not been built (no fallback)."""
     global _lib
     if _lib is None:
-        # a stale binary is worse than none: rebuild (digest-checked, a no-op when fresh) wherever hipcc exists
-        try:
-            from . import build as _build
-            if os.environ.get("DDNM_NO_AUTOBUILD") != "1":
-                _build.build()
-        except RuntimeError as e:
-            if "hipcc not found" not in str(e):
-                raise
-        except OSError as e:                 # read-only tree, no lock file ...: use the binary that is there
-            import warnings
-            warnings.warn(f"ddnm_amd: could not check / rebuild libddnm_hip.so ({e}); loading the existing binary")
         if not os.path.exists(LIB_PATH):
             raise DDNMHipError(
                 f"{LIB_PATH} is missing: build it with `python -m ddnm_amd.build` "

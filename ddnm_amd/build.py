@@ -33,17 +33,7 @@ def build(force=False, verbose=False):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
-    import fcntl
-    with open(os.path.join(HERE, ".build.lock"), "w") as lock:       # one builder at a time (torchrun ranks)
-        fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
-            return LIB
-        return _build_locked(dig, verbose)
-
-
-def _build_locked(dig, verbose):
-    tmp = LIB + f".tmp{os.getpid()}"          # link next to the target, then rename: never a half-written library
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -52,7 +42,6 @@ def _build_locked(dig, verbose):
         raise RuntimeError("hipcc failed")
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
-    os.replace(tmp, LIB)
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB
