@@ -76,4 +76,7 @@ def reduce_sum(value, device):
 
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":          # pin the RCCL barrier to this rank's GPU
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
