@@ -68,6 +68,8 @@ def main(conf, args):
         print("loading classifier...")
         classifier = create_classifier(**select_args(conf, classifier_defaults().keys()))
         classifier.load_state_dict(_state_dict(conf.classifier_path, classifier))
+        if conf.classifier_use_fp16:
+            classifier.convert_to_fp16()
         classifier.eval()
         scale = float(conf.classifier_scale)
 
