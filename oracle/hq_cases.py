@@ -31,14 +31,29 @@ CASES = {
     "colorization": dict(deg="colorization", scale=4, resize_y=False, sigma_y=0.0, gt_hw=(256, 256), **_SHORT),
     "sr_color": dict(deg="sr_color", scale=4, resize_y=False, sigma_y=0.0, gt_hw=(256, 384), **_SHORT),
 }
-for _i, _c in enumerate(CASES.values()):
+# face256-only degradations (gaussian_diffusion.py:600-622): unconditional model, keep-mask from the data loader
+FACE_CASES = {
+    "face_inpainting": dict(deg="inpainting", scale=4, resize_y=False, sigma_y=0.0, gt_hw=(256, 256), face=True, **_SHORT),
+    "face_mask_color_sr": dict(deg="mask_color_sr", scale=4, resize_y=False, sigma_y=0.0, gt_hw=(256, 256), face=True,
+                               **_SHORT),
+}
+CASES_ALL = dict(CASES, **FACE_CASES)
+for _i, _c in enumerate(CASES_ALL.values()):
     _c.setdefault("classifier", False)
     _c["class"] = 950
     _c["seed"] = cases.SEED + 40 + _i
 
 
 def model_config(case):
+    if case.get("face"):
+        return weights.adm_config(**dict(_MODEL, class_cond=False))
     return weights.adm_config(**_MODEL)
+
+
+def keep_mask(case):
+    """[1, 3, 256, 256] float keep-mask in {0, 1} (the loader's `gt_keep_mask`, image_datasets.py:167-181)."""
+    m = cases.random_mask(256).float()
+    return m.reshape(1, 1, 256, 256).repeat(1, 3, 1, 1).contiguous()
 
 
 def classifier_config(case):
@@ -55,6 +70,8 @@ def conf_dict(case):
              classifier_resblock_updown=True, classifier_pool="attention", show_progress=False,
              timestep_respacing=case["timestep_respacing"], schedule_jump_params=dict(case["schedule"]))
     d.update(_MODEL)
+    if case.get("face"):
+        d.update(name="face256", class_cond=False)
     return d
 
 

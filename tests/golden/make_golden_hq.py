@@ -56,7 +56,7 @@ def main():
         out[f"space_{key}"] = np.array(sorted(ns.respace.space_timesteps(steps, resp)))
     scratch = tempfile.mkdtemp(prefix="hq_golden_")
     os.chdir(scratch)
-    for name, case in hq_cases.CASES.items():
+    for name, case in hq_cases.CASES_ALL.items():
         conf = make_conf(ns, case)
         model, diffusion = ns.script_util.create_model_and_diffusion(
             **ns.script_util.select_args(conf, ns.script_util.model_and_diffusion_defaults().keys()), conf=conf)
@@ -92,6 +92,8 @@ def main():
         gt, x_init, tape = hq_cases.inputs(case)
         kwargs = {"gt": gt.clone(), "scale": case["scale"], "deg": case["deg"], "resize_y": case["resize_y"],
                   "sigma_y": case["sigma_y"], "save_path": name, "y": torch.full((1,), case["class"], dtype=torch.long)}
+        if case.get("face"):
+            kwargs["gt_keep_mask"] = hq_cases.keep_mask(case)
         with torch.no_grad(), ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
             res = diffusion.p_sample_loop_progressive(model_fn, (1, 3, 256, 256), noise=x_init.clone(),
                                                       clip_denoised=conf.clip_denoised, model_kwargs=kwargs,

@@ -53,13 +53,15 @@ def _oracle_models(case):
     return model, cond_fn
 
 
-@pytest.mark.parametrize("name", list(hq_cases.CASES))
+@pytest.mark.parametrize("name", list(hq_cases.CASES_ALL))
 def test_oracle_hq_demo_golden(golden, name):
-    case = hq_cases.CASES[name]
+    case = hq_cases.CASES_ALL[name]
     gt, x_init, tape = hq_cases.inputs(case)
     model, cond_fn = _oracle_models(case)
+    face = bool(case.get("face"))
     final, _, _ = H.restore(model, gt, case["deg"], case["scale"], case["sigma_y"], case["resize_y"], x_init, tape,
-                            classes=torch.full((1,), case["class"], dtype=torch.long), cond_fn=cond_fn,
+                            classes=None if face else torch.full((1,), case["class"], dtype=torch.long), cond_fn=cond_fn,
+                            mask=hq_cases.keep_mask(case) if face else None,
                             timestep_respacing=case["timestep_respacing"], schedule=case["schedule"])
     ref = torch.from_numpy(golden[f"{name}_final"])
     assert rel(final[:, :, ::4, ::4], ref) < 2e-5
@@ -154,6 +156,33 @@ def test_engine_hq_demo_vs_reference_golden(hip, golden, name, tmp_path, monkeyp
     # the reference's result files
     for sub in ("y", "Apy", "final"):
         assert (tmp_path / "results" / name / sub / "00000.png").exists()
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent: not yet run on an MI355X "
+                                        "(the oracle side is pinned by test_oracle_hq_demo_golden); remove when green")
+@pytest.mark.parametrize("name", list(hq_cases.FACE_CASES))
+def test_engine_hq_demo_face_degradations(hip, golden, name, tmp_path, monkeypatch):
+    """face256-only degradations of hq_demo (inpainting, mask_color_sr) with the loader's keep-mask."""
+    from ddnm_amd.guided_diffusion.unet import create_model
+    from ddnm_amd.hq_demo.script_util import create_gaussian_diffusion
+    monkeypatch.chdir(tmp_path)
+    case = hq_cases.FACE_CASES[name]
+    gt, x_init, tape = hq_cases.inputs(case)
+    mcfg = hq_cases.model_config(case)
+    m = create_model(**vars(mcfg.model))
+    m.load_state_dict(weights.adm_state_dict(mcfg, cases.SEED))
+    conf = hq_cases.conf_dict(case)
+    diffusion = create_gaussian_diffusion(steps=1000, learn_sigma=True, timestep_respacing=case["timestep_respacing"],
+                                          conf=conf)
+    kw = {"gt": gt.cuda(), "scale": case["scale"], "deg": case["deg"], "resize_y": False, "sigma_y": 0.0,
+          "save_path": None, "gt_keep_mask": hq_cases.keep_mask(case).cuda(),
+          "y": torch.full((1,), case["class"], dtype=torch.long).cuda()}
+    res = diffusion.p_sample_loop(lambda x, t, y=None, **k: m(x, t), (1, 3, 256, 256), noise=x_init.cuda(),
+                                  model_kwargs=kw, device="cuda", progress=False, return_all=True, conf=conf,
+                                  noise_tape=[n.cuda() for n in tape])
+    torch.cuda.synchronize()
+    assert rel(res["sample"].cpu()[:, :, ::4, ::4], torch.from_numpy(golden[f"{name}_final"])) < 3e-4
 
 
 @pytest.mark.gpu
