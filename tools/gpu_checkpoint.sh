@@ -10,7 +10,9 @@ x = torch.randn(1 << 20, device='cuda'); assert torch.isfinite((x * 2).sum()).it
 PY
 cd /root/repo
 export TMPDIR=/tmp
-timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 || { echo 'smoke() failed: stopping before the long steps'; exit 4; }
+mkdir -p gpurun_out
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; echo 'smoke() failed: stopping before the long steps'; exit 4; }
+tail -1 gpurun_out/smoke.log
 timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
 timeout 600 python bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
 cd /tmp
