@@ -108,3 +108,22 @@ def adm_forward_inputs(cfg, batch, seed=SEED + 6):
     t = torch.tensor([430.0, 990.0, 0.0, 10.0][:batch])
     y = torch.tensor([951, 3, 17, 999][:batch]) if cfg.model.class_cond else None
     return x, t, y
+
+
+# ---- simplified path (guided_diffusion/diffusion.py:211-415; batch size 1) -----------------------------------
+# sr_averagepooling / inpainting / mask_color_sr are tied to 256x256 there (AdaptiveAvgPool2d(256 // scale) :253, the
+# 256x256 exp/inp_masks/mask.npy :257), so those run a 5-level net at 256 px; colorization / denoising run at 32 px.
+SIMPLIFIED_CASES = [
+    dict(name="colorization", deg="colorization", res=32, sigma_y=0.0, T=10, travel=(2, 2)),
+    dict(name="denoising_noisy", deg="denoising", res=32, sigma_y=0.3, T=10, travel=(2, 2)),
+    dict(name="sr_averagepooling", deg="sr_averagepooling", res=256, sigma_y=0.0, T=6, travel=(2, 2)),
+    dict(name="inpainting_noisy", deg="inpainting", res=256, sigma_y=0.3, T=6, travel=(2, 2)),
+    dict(name="mask_color_sr", deg="mask_color_sr", res=256, sigma_y=0.0, T=6, travel=(2, 2)),
+]
+
+
+def simplified_net(res):
+    if res == 32:
+        return celeba_net("small")
+    cfg = weights.celeba_config(ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=1, attn_resolutions=(16,), resolution=res)
+    return cfg, weights.celeba_state_dict(cfg, SEED)

@@ -158,6 +158,86 @@ def make_cs():
     np.savez_compressed(os.path.join(HERE, "cs_blockbased.npz"), **out)
 
 
+def make_simplified():
+    """Drive the REAL `Diffusion.simplified_ddnm_plus` (guided_diffusion/diffusion.py:211-415) -- the loop is inlined
+    in a method full of dataset / image I/O, so the method runs on a bare instance with: a one-image fake dataset,
+    `tvu.save_image` capturing tensors, `data_transform` = 2x-1 and an identity `inverse_data_transform` (so the
+    captured result is unclamped), the 'cuda'->CPU shim and the noise tape (x_T is the first `torch.randn`)."""
+    import importlib
+    import types
+    ref_import.load()
+    sys.path.insert(0, ref_import.REF_ROOT)
+    try:
+        ds = types.ModuleType("datasets")
+        ds.data_transform = lambda config, X: 2 * X - 1.0                 # datasets/__init__.py:201-215, rescaled
+        ds.inverse_data_transform = lambda config, X: X                   # identity: keep the result unclamped
+        ds.get_dataset = None
+        sys.modules["datasets"] = ds
+        ck = types.ModuleType("functions.ckpt_util")
+        ck.get_ckpt_path = ck.download = None
+        sys.modules.setdefault("functions.ckpt_util", ck)
+        D = importlib.import_module("guided_diffusion.diffusion")
+    finally:
+        sys.path.remove(ref_import.REF_ROOT)
+        sys.modules.pop("datasets", None)
+    ns = ref_import.load()
+    out = {}
+    saved = {}
+    D.tvu.save_image = lambda t, path, **kw: saved.__setitem__(os.path.basename(path), t.detach().clone())
+    cwd = os.getcwd()
+    os.chdir(ref_import.REF_ROOT)                     # exp/inp_masks/mask.npy is opened relative to the cwd (:257)
+    try:
+        for case in cases.SIMPLIFIED_CASES:
+            name, deg, res, sigma_y = case["name"], case["deg"], case["res"], case["sigma_y"]
+            cfg, sd = cases.simplified_net(res)
+            tt = cfg.time_travel
+            tt.T_sampling, tt.travel_length, tt.travel_repeat = case["T"], case["travel"][0], case["travel"][1]
+            n_it = len(schedule.jump_times(tt.T_sampling, tt.travel_length, tt.travel_repeat)) - 1
+            x_orig, x_T, tape = cases.sampler_case(cfg, 1, n_it)
+            x01 = (x_orig + 1) / 2                                        # the loader yields [0,1] images
+
+            class OneImage(torch.utils.data.Dataset):
+                def __len__(self):
+                    return 1
+
+                def __getitem__(self, i):
+                    return x01[0], 0
+            D.get_dataset = lambda args, config: (None, OneImage())
+            model = ns.models.Model(cfg)
+            model.load_state_dict(sd)
+            model.eval()
+            runner = object.__new__(D.Diffusion)
+            runner.args = argparse.Namespace(deg=deg, deg_scale=4.0, sigma_y=sigma_y / 2, subset_start=-1, subset_end=-1,
+                                             seed=1234, image_folder=os.path.join("/tmp", "ddnm_simplified_golden", name),
+                                             eta=0.85)
+            runner.config, runner.device, runner.betas = cfg, torch.device("cpu"), cases.betas()
+            saved.clear()
+            orig_randn = torch.randn
+            first = {"done": False}
+
+            def randn(*a, **k):                       # x_T (:323-329) is the only torch.randn of the method
+                if not first["done"] and tuple(a[:4]) == tuple(x_T.shape):
+                    first["done"] = True
+                    return x_T.clone()
+                k.pop("device", None)
+                return orig_randn(*a, **k)
+            torch.randn = randn
+            try:
+                with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape):
+                    runner.simplified_ddnm_plus(model, None)
+            finally:
+                torch.randn = orig_randn
+            final = [v for k, v in saved.items() if k == "-1_0.png"]       # the stale loop variable j = -1 (:402)
+            assert len(final) == 1 and first["done"], (list(saved), first)
+            full = final[0][None]
+            out[f"{name}_x"] = (full if res == 32 else full[..., ::4, ::4]).contiguous().numpy()
+            out[f"{name}_stats"] = np.array([full.double().mean().item(), full.double().std().item(),
+                                             full.double().abs().sum().item()])
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "simplified.npz"), **out)
+
+
 def make_plus():
     """ddnm_plus_diffusion (functions/svd_ddnm.py:80-164) of the reference: small celeba net, sigma_y = 0.2
     (doubled value, as the runner passes it), 20 steps with time travel, every operator that has Lambda."""
@@ -261,6 +341,7 @@ def main():
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
     ap.add_argument("--plus-deblur-only", action="store_true", help="only (re)generate the DDNM+ deblurring goldens")
+    ap.add_argument("--simplified-only", action="store_true", help="only (re)generate the simplified-loop goldens")
     ap.add_argument("--cs-only", action="store_true", help="only (re)generate the block-based CS goldens")
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
@@ -269,6 +350,8 @@ def main():
         return make_classifier()
     if args.plus_deblur_only:
         return make_plus_deblur()
+    if args.simplified_only:
+        return make_simplified()
     if args.cs_only:
         return make_cs()
     if args.deblur_only:

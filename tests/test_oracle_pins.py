@@ -170,3 +170,37 @@ def test_reference_simplified_loop_restatement():
     from oracle import operators as O
     assert torch.equal(D.color2gray(x), O.color2gray(x)) and torch.equal(D.gray2color(x), O.gray2color(x))
     assert D.get_schedule_jump(100, 10, 3) == schedule.jump_times(100, 10, 3)
+
+
+@pytest.mark.parametrize("case", cases.SIMPLIFIED_CASES, ids=[c["name"] for c in cases.SIMPLIFIED_CASES])
+def test_oracle_simplified_loop_golden(case, golden_dir):
+    """`sampler.simplified_ddnm` + the A / Ap lambdas of the simplified path against goldens produced by driving the
+    REAL `Diffusion.simplified_ddnm_plus` (tests/golden/make_golden.py::make_simplified): colorization, noisy
+    denoising, average-pool SR, noisy inpainting with the repository mask, and the composed mask_color_sr."""
+    from oracle import operators as O
+    g = np.load(f"{golden_dir}/simplified.npz")
+    cfg, sd = cases.simplified_net(case["res"])
+    T, (tl, tr) = case["T"], case["travel"]
+    n_it = len(schedule.jump_times(T, tl, tr)) - 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 1, n_it)
+    d, deg = case["res"], case["deg"]
+    mask = None
+    if deg in ("inpainting", "mask_color_sr"):
+        mask = real_mask(golden_dir)                                         # exp/inp_masks/mask.npy, committed packed
+    if deg == "colorization":
+        A, Ap = O.color2gray, O.gray2color
+    elif deg == "denoising":
+        A = Ap = lambda z: z                                                 # noqa: E731
+    elif deg == "sr_averagepooling":
+        A = torch.nn.AdaptiveAvgPool2d((256 // 4, 256 // 4))
+        Ap = lambda z: sampler.mean_upsample(z, 4)                           # noqa: E731
+    elif deg == "inpainting":
+        A = Ap = lambda z: z * mask                                          # noqa: E731
+    else:
+        A, Ap = O.mask_color_sr(mask, 4, d)
+    x, _ = sampler.simplified_ddnm(x_T.clone(), unet_celeba.Net(sd, cfg), cases.betas(), 0.85, A, Ap, A(x_orig),
+                                   case["sigma_y"], tape, T_sampling=T, travel_length=tl, travel_repeat=tr)
+    got = x if d == 32 else x[..., ::4, ::4]
+    assert rel(got, torch.from_numpy(g[f"{case['name']}_x"])) < 2e-5
+    st = g[f"{case['name']}_stats"]
+    assert abs(x.double().abs().sum().item() - st[2]) < 2e-5 * st[2]
