@@ -62,6 +62,8 @@ def schedule_jump(t_T, n_sample, jump_length, jump_n_sample, jump2_length=1, jum
 def space_timesteps(num_timesteps, section_counts):
     """respace.py:23-77 for the "N" / "a,b,c" forms used by the configs."""
     counts = [int(v) for v in str(section_counts).split(",")]
+    if len(counts) == 1 and counts[0] > num_timesteps:                  # more steps than the process has (:52-53)
+        return sorted(set(np.linspace(start=0, stop=num_timesteps, num=counts[0])))
     size_per, extra = divmod(num_timesteps, len(counts))
     start, steps = 0, []
     for i, c in enumerate(counts):

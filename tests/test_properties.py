@@ -14,7 +14,7 @@ from oracle import hq_demo as H
 from oracle import schedule
 
 
-@settings(max_examples=200, deadline=None)
+@settings(max_examples=200, deadline=None, derandomize=True)
 @given(st.integers(256, 1300), st.integers(256, 1300))
 def test_tile_plan_covers_image_and_strips_are_restored(h, w):
     plan = tile_plan(h, w)
@@ -31,7 +31,7 @@ def test_tile_plan_covers_image_and_strips_are_restored(h, w):
     assert done.all()
 
 
-@settings(max_examples=200, deadline=None)
+@settings(max_examples=200, deadline=None, derandomize=True)
 @given(st.integers(2, 120), st.integers(1, 12), st.integers(1, 4))
 def test_ddnm_schedule_matches_oracle(t_sampling, travel_length, travel_repeat):
     times = get_schedule_jump(t_sampling, travel_length, travel_repeat)
@@ -41,7 +41,7 @@ def test_ddnm_schedule_matches_oracle(t_sampling, travel_length, travel_repeat):
     assert sum(1 for a, b in zip(times[:-1], times[1:]) if b < a) >= t_sampling      # every step is denoised at least once
 
 
-@settings(max_examples=150, deadline=None)
+@settings(max_examples=150, deadline=None, derandomize=True)
 @given(st.integers(4, 120), st.integers(1, 3), st.integers(1, 12), st.integers(1, 4), st.integers(1, 4), st.integers(1, 3))
 def test_hq_schedule_matches_oracle(t_T, n_sample, jump_length, jump_n_sample, jump2_length, jump2_n_sample):
     kw = dict(t_T=t_T, n_sample=n_sample, jump_length=jump_length, jump_n_sample=jump_n_sample,
@@ -51,7 +51,7 @@ def test_hq_schedule_matches_oracle(t_T, n_sample, jump_length, jump_n_sample, j
     assert ts[0] == t_T - 1 and ts[-1] == -1 and max(ts) <= t_T - 1 + max(jump_length, jump2_length, 1)
 
 
-@settings(max_examples=150, deadline=None)
+@settings(max_examples=150, deadline=None, derandomize=True)
 @given(st.integers(8, 1000), st.lists(st.integers(1, 40), min_size=1, max_size=4))
 def test_space_timesteps_matches_oracle(steps, counts):
     spec = ",".join(str(c) for c in counts)
@@ -66,10 +66,12 @@ def test_space_timesteps_matches_oracle(steps, counts):
         except ValueError:
             return
     got = sorted(space_timesteps(steps, spec))
-    assert got == want and got[0] == 0 and got[-1] <= steps - 1
+    assert got == want and got[0] == 0
+    if not (len(counts) == 1 and counts[0] > steps):          # (the oversampling special case ends AT `steps`)
+        assert got[-1] <= steps - 1
 
 
-@settings(max_examples=200, deadline=None)
+@settings(max_examples=200, deadline=None, derandomize=True)
 @given(st.integers(0, 500), st.integers(1, 16))
 def test_shard_range_partitions(n, world):
     ranges = [ddist.shard_range(n, r, world) for r in range(world)]
