@@ -24,7 +24,10 @@ def space_timesteps(num_timesteps, section_counts):
         if size < count:
             raise ValueError(f"cannot divide section of {size} steps into {count}")
         stride = 1 if count <= 1 else (size - 1) / (count - 1)
-        steps.extend(start + round(k * stride) for k in range(count))
+        pos = 0.0
+        for _ in range(count):          # the reference accumulates the fractional stride (k * stride rounds differently)
+            steps.append(start + round(pos))
+            pos += stride
         start += size
     return set(steps)
 

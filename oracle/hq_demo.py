@@ -71,7 +71,10 @@ def space_timesteps(num_timesteps, section_counts):
         if size < c:
             raise ValueError(f"cannot divide section of {size} steps into {c}")
         stride = 1 if c <= 1 else (size - 1) / (c - 1)
-        steps += [start + round(k * stride) for k in range(c)]
+        cur = 0.0
+        for _ in range(c):                       # running float sum, rounded half-to-even, exactly like :66-70
+            steps.append(start + round(cur))
+            cur += stride
         start += size
     return sorted(set(steps))
 

@@ -204,3 +204,70 @@ def test_oracle_simplified_loop_golden(case, golden_dir):
     assert rel(got, torch.from_numpy(g[f"{case['name']}_x"])) < 2e-5
     st = g[f"{case['name']}_stats"]
     assert abs(x.double().abs().sum().item() - st[2]) < 2e-5 * st[2]
+
+
+@needs_ref
+def test_schedules_match_reference_on_random_parameters():
+    """The DDNM time-travel schedule (functions/svd_ddnm.py:167-206) on 3000 random (T, length, repeat) triples:
+    reference == oracle == engine, including the parameter sets the reference rejects."""
+    import random
+    from ddnm_amd.functions.svd_ddnm import get_schedule_jump
+    ns = ref_import.load()
+    rnd = random.Random(5)
+    for _ in range(3000):
+        T, tl, tr = rnd.randint(1, 150), rnd.randint(1, 15), rnd.randint(1, 5)
+        outs = []
+        for fn in (ns.svd_ddnm.get_schedule_jump, schedule.jump_times, get_schedule_jump):
+            try:
+                outs.append(fn(T, tl, tr))
+            except AssertionError:
+                outs.append("assert")
+        assert outs[0] == outs[1] == outs[2], (T, tl, tr)
+
+
+def test_hq_host_logic_matches_reference_on_random_parameters():
+    """hq_demo's scheduler and respacing (hq_demo/guided_diffusion/{scheduler,respace}.py) on random parameters:
+    reference == oracle == engine (run in a subprocess: hq_demo's `guided_diffusion` package shadows the main one)."""
+    import os
+    import subprocess
+    import sys
+    if not ref_import.available():
+        pytest.skip("/root/reference not present on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, types, random, importlib
+sys.modules.setdefault("blobfile", types.ModuleType("blobfile"))
+sys.path.insert(0, HQ)
+sch = importlib.import_module("guided_diffusion.scheduler")
+rsp = importlib.import_module("guided_diffusion.respace")
+sys.path.pop(0)
+sys.path.insert(0, ROOT)
+from oracle import hq_demo as H
+from ddnm_amd.hq_demo import get_schedule_jump, space_timesteps
+rnd = random.Random(7)
+for _ in range(2000):
+    kw = dict(t_T=rnd.randint(2, 120), n_sample=rnd.randint(1, 3), jump_length=rnd.randint(1, 15),
+              jump_n_sample=rnd.randint(1, 5), jump2_length=rnd.randint(1, 6), jump2_n_sample=rnd.randint(1, 3),
+              jump3_length=rnd.randint(1, 4), jump3_n_sample=rnd.randint(1, 3),
+              start_resampling=rnd.choice([100000000, 50, 20]))
+    outs = []
+    for fn in (sch.get_schedule_jump, H.schedule_jump, get_schedule_jump):
+        try:
+            outs.append(fn(**kw))
+        except AssertionError:
+            outs.append("assert")
+    assert outs[0] == outs[1] == outs[2], kw
+for _ in range(5000):
+    steps = rnd.randint(2, 1200)
+    spec = ",".join(str(rnd.randint(1, 60)) for _ in range(rnd.randint(1, 4)))
+    outs = []
+    for fn in (rsp.space_timesteps, H.space_timesteps, space_timesteps):
+        try:
+            outs.append(sorted(fn(steps, spec)))
+        except ValueError:
+            outs.append("ValueError")
+    assert outs[0] == outs[1] == outs[2], (steps, spec)
+print("OK")
+'''.replace("HQ", repr(os.path.join(ref_import.REF_ROOT, "hq_demo"))).replace("ROOT", repr(root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
