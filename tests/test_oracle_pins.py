@@ -271,3 +271,86 @@ print("OK")
 '''.replace("HQ", repr(os.path.join(ref_import.REF_ROOT, "hq_demo"))).replace("ROOT", repr(root))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@needs_ref
+@pytest.mark.parametrize("factor", [2, 4, 8, 16])
+def test_bicubic_and_gaussian_kernels_match_reference_source(factor):
+    """The operator factory of the reference is inlined in `svd_based_ddnm_plus` (diffusion.py:451-523) and cannot be
+    imported; its kernel-building statements are executed verbatim from the source file here and compared with the
+    oracle's and the engine's builders (bit-exact)."""
+    import os
+    import textwrap
+    from oracle import operators as O
+    from ddnm_amd.functions import svd_operators as E
+    src = open(os.path.join(ref_import.REF_ROOT, "guided_diffusion", "diffusion.py")).read().split("\n")
+    a = next(i for i, l in enumerate(src) if "def bicubic_kernel(x, a=-0.5):" in l)
+    b = next(i for i, l in enumerate(src) if "kernel = torch.from_numpy(k).float()" in l)
+    block = textwrap.dedent("\n".join(src[a:b + 1])).replace(".to(self.device)", "")
+    env = {"np": np, "torch": torch, "factor": factor}
+    exec(block, env)                                                       # noqa: S102 (reference source, test only)
+    ref = env["kernel"] / env["kernel"].sum()                              # the argument SRConv receives (:498)
+    assert torch.equal(O.bicubic_kernel(factor), ref)
+    assert torch.equal(E.bicubic_kernel(factor), ref)
+    if factor == 2:
+        for sigma, radius, marker in ((10, 2, "sigma = 10"), (20, 4, "sigma = 20"), (1, 4, "sigma = 1\n")):
+            pdf = lambda x: torch.exp(torch.Tensor([-0.5 * (x / sigma) ** 2]))        # noqa: E731  (:507,513,517)
+            want = torch.Tensor([pdf(x) for x in range(-radius, radius + 1)])
+            assert torch.equal(O.gaussian_taps(sigma, radius), want)
+            assert torch.equal(E.gaussian_taps(sigma, radius), want)
+
+
+@needs_ref
+def test_beta_schedules_and_alpha_table_match_reference():
+    """`get_beta_schedule` for every schedule name (diffusion.py:46-76) and `compute_alpha` for every t in
+    [-1, 999] (svd_ddnm.py:10-13): reference == engine, bit for bit."""
+    import importlib
+    import sys
+    import types
+    from ddnm_amd.functions.svd_ddnm import _AlphaTable, compute_alpha
+    from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
+    ns = ref_import.load()
+    sys.path.insert(0, ref_import.REF_ROOT)
+    try:
+        sys.modules.setdefault("datasets", types.ModuleType("datasets"))
+        for attr in ("get_dataset", "data_transform", "inverse_data_transform"):
+            setattr(sys.modules["datasets"], attr, None)
+        ck = types.ModuleType("functions.ckpt_util")
+        ck.get_ckpt_path = ck.download = None
+        sys.modules.setdefault("functions.ckpt_util", ck)
+        D = importlib.import_module("guided_diffusion.diffusion")
+    finally:
+        sys.path.remove(ref_import.REF_ROOT)
+        sys.modules.pop("datasets", None)
+    for name in ("quad", "linear", "const", "jsd", "sigmoid"):
+        for n in (10, 1000):
+            kw = dict(beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=n)
+            assert np.array_equal(D.get_beta_schedule(name, **kw), get_beta_schedule(name, **kw)), name
+    betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
+                                               num_diffusion_timesteps=1000)).float()
+    table = _AlphaTable(betas)
+    for t in range(-1, 1000):
+        tt = torch.full((2,), t, dtype=torch.long)
+        want = ns.svd_ddnm.compute_alpha(betas, tt)
+        assert torch.equal(compute_alpha(betas, tt), want)
+        assert float(table(t)) == float(want[0, 0, 0, 0])
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_inpainting_real_constructor_small(seed):
+    """The REAL `Inpainting.__init__` (its O(n*m) kept-index loop, svd_operators.py:324-333) at 16x16 -- the golden
+    generator bypasses it at full size -- against the oracle operator: A, A_pinv and the index order."""
+    from oracle import operators as O
+    ns = ref_import.load()
+    g = torch.Generator().manual_seed(seed)
+    d = 16
+    mask = (torch.rand(d, d, generator=g) > 0.3).long()
+    r = torch.nonzero(mask.reshape(-1) == 0).long().reshape(-1) * 3                    # diffusion.py:465-470
+    missing = torch.cat([r, r + 1, r + 2], dim=0)
+    ref = ns.svd_operators.Inpainting(3, d, missing, "cpu")
+    orc = O.Inpainting(3, d, O.Inpainting.missing_from_mask(mask))
+    x = torch.randn(2, 3, d, d, generator=g)
+    y = ref.A(x)
+    assert torch.equal(orc.A(x), y)
+    assert torch.equal(orc.A_pinv(y).reshape(2, -1), ref.A_pinv(y.clone()).reshape(2, -1))
