@@ -19,7 +19,15 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-constexpr int KC16 = 64;            // channels per chunk
+// Build-time tile variants for probing (tools/conv16_ablate.py): -DDDNM_F16_KC=32 -DDDNM_F16_BM=512 is the 8-wave
+// 512x128 block with 128x64 wave tiles (25 % fewer LDS fragment reads per MFMA); defaults = the production tile.
+#ifndef DDNM_F16_KC
+#define DDNM_F16_KC 64
+#endif
+#ifndef DDNM_F16_BM
+#define DDNM_F16_BM 256
+#endif
+constexpr int KC16 = DDNM_F16_KC;   // channels per chunk
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 
 // SRC16 = the activation operand is already fp16 in HBM (written by ddnm_gn_apply_f16: GroupNorm affine +
@@ -29,12 +37,13 @@ template <int WM, int WN, int MT, int NT, bool SRC16>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int MAXH = BM == 256 ? 340 : (BM == 128 ? 204 : 136);
+    constexpr int MAXH = BM == 512 ? 612 : (BM == 256 ? 340 : (BM == 128 ? 204 : 136));
     constexpr int HVEC = SRC16 ? 8 : 4;                           // channels per 16-byte global load
     constexpr int HCOLS = KC16 / HVEC;                            // loads per 64-channel halo row
     constexpr int HROWS_PER_PASS = NTHREADS / HCOLS;
     constexpr int HR = (MAXH + HROWS_PER_PASS - 1) / HROWS_PER_PASS;
-    constexpr int BROWS_PER_PASS = NTHREADS / 8;                  // 8 x 16 B per 64-half weight row
+    constexpr int BCOLS = KC16 / 8;                               // 16-byte pieces per weight row of one chunk
+    constexpr int BROWS_PER_PASS = NTHREADS / BCOLS;
     constexpr int BR = BN / BROWS_PER_PASS;
     static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
     __shared__ __attribute__((aligned(16))) _Float16 Hs[2 * MAXH * LDH];      // halo double-buffered (see main loop)
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         hoff[i] = ok ? (img * p.Hs + sy) * p.Ws + sx : -1;
     }
     // ---- weight loader mapping: thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
-    const int c8 = tid & 7, brow = tid >> 3;
+    const int c8 = tid % BCOLS, brow = tid / BCOLS;
     const _Float16* wbase = reinterpret_cast<const _Float16*>(d.weight) + (size_t)(n_tile * BN + brow) * 9 * p.Cin + c8 * 8;
 
     const int nchunks = p.Cin / KC16;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     // named registers, not an array: the compiler kept `uint4 b_st[BR]` in memory (promoted to a 16 KB LDS array),
     // which turned every weight prefetch into load -> wait -> LDS -> barrier -> LDS -> LDS and exposed the full
     // global-load latency once per tap
-    static_assert(BR == 2 || BR == 4, "weight staging registers");
+    static_assert(BR == 1 || BR == 2 || BR == 4, "weight staging registers");
     uint4 b_st0 = {0u, 0u, 0u, 0u}, b_st1 = {0u, 0u, 0u, 0u}, b_st2 = {0u, 0u, 0u, 0u}, b_st3 = {0u, 0u, 0u, 0u};
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
     const bool has_gn = !SRC16 && d.gn_scale != nullptr;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         if (chunk < 0) {
 #endif
         b_st0 = *reinterpret_cast<const uint4*>(wp);
-        b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin);
+        if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin);
         if constexpr (BR == 4) {
             b_st2 = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * BROWS_PER_PASS) * 9 * p.Cin);
             b_st3 = *reinterpret_cast<const uint4*>(wp + (size_t)(3 * BROWS_PER_PASS) * 9 * p.Cin);
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     auto stage_b = [&](int buf) {
         _Float16* dst = &Bs[buf * BN * LDH + brow * LDH + c8 * 8];
         *reinterpret_cast<uint4*>(dst) = b_st0;
-        *reinterpret_cast<uint4*>(dst + BROWS_PER_PASS * LDH) = b_st1;
+        if constexpr (BR >= 2) *reinterpret_cast<uint4*>(dst + BROWS_PER_PASS * LDH) = b_st1;
         if constexpr (BR == 4) {
             *reinterpret_cast<uint4*>(dst + 2 * BROWS_PER_PASS * LDH) = b_st2;
             *reinterpret_cast<uint4*>(dst + 3 * BROWS_PER_PASS * LDH) = b_st3;
@@ -233,12 +242,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin + c8 * 8;
         // the raw input is fp32: thread -> (float4 column sc of 16, interior pixels srow + 32*i), staged at the
         // pixel's halo position so that mfma_tap(4) (centre tap) reads it
-        constexpr int SR = BM * 16 / NTHREADS;
-        const int sc = tid & 15, srow = tid >> 4;
+        constexpr int SCOLS = KC16 / 4;                            // float4 pieces per raw-input row of one chunk
+        constexpr int SR = BM * SCOLS / NTHREADS;
+        const int sc = tid % SCOLS, srow = tid / SCOLS;
         int soff[SR], sdst[SR];
 #pragma unroll
         for (int i = 0; i < SR; ++i) {
-            const int m = srow + (NTHREADS / 16) * i;
+            const int m = srow + (NTHREADS / SCOLS) * i;
             const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
             const int iy = tm.ty0 + ty, ix = tm.tx0 + tx;
             const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #pragma unroll
             for (int i = 0; i < SR; ++i) s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)soff[i] * cs + coff + sc * 4);
             b_st0 = *reinterpret_cast<const uint4*>(swbase + cb);
-            b_st1 = *reinterpret_cast<const uint4*>(swbase + (size_t)BROWS_PER_PASS * SCin + cb);
+            if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(swbase + (size_t)BROWS_PER_PASS * SCin + cb);
             if constexpr (BR == 4) {
                 b_st2 = *reinterpret_cast<const uint4*>(swbase + (size_t)(2 * BROWS_PER_PASS) * SCin + cb);
                 b_st3 = *reinterpret_cast<const uint4*>(swbase + (size_t)(3 * BROWS_PER_PASS) * SCin + cb);
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             mfma_tap(4, 0);
         }
     }
-    conv_epilogue<WM, WN, MT, NT, true>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
+    conv_epilogue<WM, WN, MT, NT, (MT * NT <= 4)>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -289,7 +299,7 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl) {
     const int Cin = d->C0 + d->C1;
     if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hin || d->Wo != d->Win) return false;
     if (Cin % KC16 || d->C0 % KC16 || d->Cout % 128 || d->out_nchw) return false;
-    pl->BM = 256;
+    pl->BM = DDNM_F16_BM;
     if (HWo % pl->BM) return false;
     int tw = 32;
     while (tw > 8 && (d->Wo % tw || d->Ho % (pl->BM / tw))) tw >>= 1;
@@ -362,7 +372,10 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     p.ws = d->workspace;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(p.m_tiles * p.n_tiles, pl.ksplit);
-#ifdef DDNM_F16_WAVE128        // probe: 4 waves with 128x64 wave tiles (25 % fewer LDS fragment reads per MFMA)
+#if DDNM_F16_BM == 512         // probe: 8 waves with 128x64 wave tiles over a 512-pixel patch
+    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 4, 2, true>), grid, dim3(512), 0, s, p); }
+    else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 4, 2, false>), grid, dim3(512), 0, s, p); }
+#elif defined(DDNM_F16_WAVE128)  // probe: 4 waves with 128x64 wave tiles (1 wave per SIMD)
     if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
 #else
