@@ -195,6 +195,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     // too -- the next chunk's halo is loaded in two halves (taps 0 and 3) and converted / GroupNorm'd / written
     // to the OTHER halo buffer at taps 3 and 6, between MFMA batches, so a chunk boundary costs nothing
     // (re-staging it between two barriers used to be 28 % of the kernel).
+#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
+    if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         prefetch_b(c_begin, 0);
@@ -223,7 +226,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                 // them behind the MFMAs (VGPR pressure) and their latency lands on the barrier of every tap
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef DDNM_PROBE_SETPRIO_MFMA      // probe: the MFMA burst of a tap at raised wave priority
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 mfma_tap(tap, cur, hb);
+#ifdef DDNM_PROBE_SETPRIO_MFMA
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef DDNM_PROBE16_NO_TAP_BARRIER
                 __syncthreads();
 #endif

@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 #ifndef DDNM_HALO_SINGLE_BUFFER
     // ---- weight tile double-buffered: per tap  [write B(s+1) -> other buffer | issue loads B(s+2) |
     //      MFMA(s) | barrier];  the halo is re-staged between two barriers at every chunk boundary.
+#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
+    if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         prefetch_b(c_begin, 0);
@@ -190,7 +193,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
                     else if (tap == 7) { if (more) { prefetch_b(chunk + 1, 0); prefetch_halo(chunk + 1); } }
                     else if (more) prefetch_b(chunk + 1, 1);
                 }
+#ifdef DDNM_PROBE_SETPRIO_MFMA      // probe: the MFMA burst of a tap at raised wave priority
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 mfma_tap(tap, cur);
+#ifdef DDNM_PROBE_SETPRIO_MFMA
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 __syncthreads();
                 if (last_tap && more) {                     // chunk boundary: every wave is done with Hs
                     stage_halo();

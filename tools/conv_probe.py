@@ -20,8 +20,9 @@ CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
 OUT = os.path.join(ROOT, "gpurun_out")
 
 VARIANTS = {
-    "dbuf": [],
-    "nosched": ["-DDDNM_PROBE_NO_SCHED_BARRIER"],
+    "base": [],
+    "prio_mfma": ["-DDDNM_PROBE_SETPRIO_MFMA"],
+    "prio_half": ["-DDDNM_PROBE_SETPRIO_HALF"],
 }
 
 # (name, B, C0, C1, Cout, H (input, pre-upsample), k, stride, ups, gn, res, tile)
