@@ -45,6 +45,20 @@ class GemmDesc(Structure):
     ]
 
 
+class Conv16Desc(Structure):
+    _fields_ = [
+        ("src", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("res", c_void_p),
+        ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
+        ("out", c_void_p), ("stats_out", c_void_p),
+        ("workspace", c_void_p), ("workspace_floats", c_int64),
+        ("B", c_int32), ("H", c_int32), ("W", c_int32),
+        ("Cin", c_int32), ("Cout", c_int32), ("ksize", c_int32),
+        ("ups", c_int32), ("res_ups", c_int32),
+        ("SC0", c_int32), ("SC1", c_int32),
+        ("out_nchw_f32", c_int32), ("reserved", c_int32),
+    ]
+
+
 class StepScalars(Structure):
     _fields_ = [("sqrt_1m_at", c_float), ("sqrt_at", c_float), ("sqrt_at_next", c_float),
                 ("c1", c_float), ("c2", c_float), ("lam", c_float)]
@@ -80,6 +94,17 @@ PROTOTYPES = {
     "ddnm_conv3x3_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv16": (c_int32, [POINTER(Conv16Desc), c_void_p]),
+    "ddnm_conv16_supported": (c_int32, [POINTER(Conv16Desc)]),
+    "ddnm_conv16_workspace_floats": (c_int64, [POINTER(Conv16Desc)]),
+    "ddnm_conv16_stats_tiles": (c_int32, [POINTER(Conv16Desc)]),
+    "ddnm_gn_apply_h16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_im2col3x3_h16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                     c_int32, c_int32, c_void_p]),
+    "ddnm_nchw_to_nhwc_h16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_gn_stats_h16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_attn16_d64": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_conv1x1_f16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv1x1_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv1x1_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),

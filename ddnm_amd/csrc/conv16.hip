@@ -1,0 +1,622 @@
+// fp16-activation implicit-GEMM convolution for the ADM `use_fp16` torso (guided_diffusion/unet.py:619-625,
+// fp16_util.py:15-22), gfx950.  Second-generation kernel of the fp16 path:
+//
+//   * every tensor it touches in HBM is fp16 NHWC: the operand was normalised / activated ONCE by
+//     ddnm_gn_apply_h16 (act16.hip), the output (+ bias + residual) is written as fp16 together with the fp32
+//     GroupNorm partials of the ROUNDED values, so the consumer never re-reads it for statistics;
+//   * block tile 256 (or 128) pixels x 256 output channels, 8 waves as 2 (pixels) x 4 (channels), wave tile
+//     128 x 64 = 4 x 2 MFMA tiles of v_mfma_f32_32x32x16_f16: 6 ds_read_b128 per 8 MFMAs (the first-generation
+//     64 x 64 wave tile needed 8 per 8 and was LDS-read bound);
+//   * both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass):
+//     the LDS image is lane-linear [row][64 channels = 128 B]; bank conflicts of the fragment reads are removed
+//     by an XOR swizzle of the 16-byte piece index with (row >> 1) & 7, applied to the per-lane SOURCE address
+//     and to the read address (the destination of an LDS-DMA cannot be permuted);
+//   * zero padding and ragged tiles read a 128-byte zero page instead of branching;
+//   * MFMA operands are swapped (A = weights, B = pixels): a lane then owns ONE pixel and 4 consecutive
+//     channels per accumulator quad, which makes the epilogue's LDS transposition ds_write_b64 / ds_read_b128
+//     and every global store a full 16 bytes per lane (8 lanes = one 128-byte line).
+//
+// K loop: chunk = 64 input channels; per chunk the (TH+2) x (TW+2) halo is resident (double-buffered, the next
+// chunk's halo is requested at tap 0) and the 9 taps read it at shifted rows; the [256][64] weight tile of the
+// next tap is requested right after the barrier that frees its buffer -- one barrier per 32 MFMAs per wave.
+// 1x1 convolutions / the im2col'ed 8x8 level run the same loop with one tap and a flat row mapping.
+#include "conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+
+struct Conv16Args {
+    ddnm_conv16_desc d;
+    int TW, TW_log2, tiles_x, tiles_per_img;   // 3x3: 2-D patch TH x TW of one image; 1x1: unused
+    int m_tiles, n_tiles, ksplit, M;           // M = B*H*W output pixels
+    int Hs, Ws;                                // source resolution (H/2 when ups)
+};
+
+constexpr int C16_KC = 64;          // channels per chunk (= 128 bytes per LDS row)
+constexpr int C16_BN = 256;
+constexpr int C16_ROWB = 128;       // LDS row pitch in bytes
+constexpr int C16_EPITCH = 144;     // epilogue staging pitch (bytes) per pixel of a wave's 64-channel slice
+
+// WNW = waves along the output-channel axis: 4 -> 2 x 4 waves, wave tile (MT*32) x 64, block (MT*64) x 256;
+//                                             1 -> 8 x 1 waves, wave tile 32 x 32, block 256 x 32 (small-Cout output conv)
+template <int TAPS, int MT, int WNW>
+struct C16Geom {
+    static constexpr int WMW = 8 / WNW, NT = WNW == 4 ? 2 : 1;
+    static constexpr int BM = WMW * MT * 32, BN = WNW * NT * 32;
+    // rows of one halo buffer, rounded up to whole 8-row (1 KB) LDS-DMA pieces
+    static constexpr int HROWS = TAPS == 9 ? (BM == 256 ? 344 : 208) : BM;
+    static constexpr int HGROUPS = HROWS / 8;
+    static constexpr int HG_PER_WAVE = (HGROUPS + 7) / 8;
+    static constexpr int HBYTES = HROWS * C16_ROWB;
+    static constexpr int WBYTES = BN * C16_ROWB;                        // 32 KB (4 KB)
+    static constexpr int LDS_MAIN = 2 * HBYTES + 2 * WBYTES;
+    static constexpr int LDS_EPI = WNW == 4 ? 8 * (MT * 32) * C16_EPITCH + 2 * C16_BN * 2 * 4 : 0;
+    static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+};
+
+// LDS-DMA of 16 bytes per lane through a raw buffer descriptor: per-lane 32-bit byte offset + wave-uniform SGPR
+// offset; an offset beyond the descriptor's size returns ZERO (that is how padding and ragged rows are fetched).
+__device__ __forceinline__ void bload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+constexpr unsigned C16_OOB = 0x80000000u;      // every tensor here is < 2 GB
+
+template <int TAPS, int MT, int WNW>
+__global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
+    using G = C16Geom<TAPS, MT, WNW>;
+    constexpr int BM = G::BM, NT = G::NT, BN = G::BN;
+    __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];     // ONE shared object (keeps the DMA pipeline)
+    char* const Hb = lds;
+    char* const Wb = lds + 2 * G::HBYTES;
+
+    const ddnm_conv16_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = WNW == 4 ? wave >> 2 : wave, wn = WNW == 4 ? wave & 3 : 0;
+    const int kh = lane >> 5;
+    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
+    const int slice = blockIdx.y;
+    const int Cin = d.Cin;
+
+    // ---- tile geometry
+    int img = 0, ty0 = 0, tx0 = 0;
+    const int TW = p.TW, TWl = p.TW_log2, HWd = TW + 2;
+    if (TAPS == 9) {
+        img = m_tile / p.tiles_per_img;
+        const int t = m_tile - img * p.tiles_per_img;
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        ty0 = ty * (BM >> TWl);
+        tx0 = tx << TWl;
+    }
+    const int NP = TAPS == 9 ? ((BM >> TWl) + 2) * HWd : BM;
+
+    // ---- LDS-DMA source mapping.  One instruction moves 8 rows x 128 B; lane -> (row = 8*g + lane/8, piece lane%8),
+    // and the piece it FETCHES is piece ^ swizzle(row) so that the linear image holds the swizzled layout.
+    const int lrow = lane >> 3, lpiece = lane & 7;
+    int hoff[G::HG_PER_WAVE];           // source pixel index (element offset / Cin) or -1 -> zero page
+    // logical piece (in halfs) this lane fetches: row = (wave + 8*gi)*8 + lrow, so (row >> 1) & 7 does not depend on gi
+    const int lp8 = (lpiece ^ (((wave & 1) << 2) | (lrow >> 1))) * 8;
+#pragma unroll
+    for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) {
+        const int row = (wave + 8 * gi) * 8 + lrow;
+        int off = -1;
+        if (TAPS == 9) {
+            if (row < NP) {
+                const int hy = row / HWd, hx = row - hy * HWd;
+                const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+                if ((unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
+                    const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+                    off = (img * p.Hs + sy) * p.Ws + sx;
+                }
+            }
+        } else {
+            const int pix = m_tile * BM + row;
+            if (row < BM && pix < p.M) off = pix;
+        }
+        hoff[gi] = off;
+    }
+    // weight rows: 32 pieces of 8 rows, wave w takes pieces w, w+8, w+16, w+24
+    const unsigned wrow0 = (unsigned)(n_tile * BN + wave * 8 + lrow);
+    const unsigned src_pix = (unsigned)d.B * p.Hs * p.Ws, out_pix = (unsigned)p.M;
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(d.src, src_pix * Cin * 2u);
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(d.weight, (unsigned)p.n_tiles * BN * TAPS * Cin * 2u);
+
+    // halo rows of channels [coff, coff+64) of the NHWC tensor behind `rsrc` (`cstride` channels per pixel)
+    auto issue_halo = [&](__amdgpu_buffer_rsrc_t rsrc, int cstride, int coff, int hb) {
+        char* dst = Hb + hb * G::HBYTES + wave * 1024;
+#pragma unroll
+        for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) {
+            if (wave + 8 * gi < G::HGROUPS) {
+                const unsigned vo = hoff[gi] >= 0 ? ((unsigned)hoff[gi] * (unsigned)cstride + lp8) * 2u : C16_OOB;
+                bload16(rsrc, vo, (unsigned)coff * 2u, dst + gi * 8192);
+            }
+        }
+    };
+    // rows n = wrow0 + 64*j of the [Cout][rowlen] fp16 matrix behind `rsrc`, 64 channels at element offset `delta`
+    auto issue_w = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned rowlen, unsigned delta, int wb) {
+        char* dst = Wb + wb * G::WBYTES + wave * 1024;
+        const unsigned vo = (wrow0 * rowlen + lp8) * 2u;
+        if (WNW == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bload16(rsrc, vo, (delta + 64u * j * rowlen) * 2u, dst + j * 8192);
+        } else if (wave < BN / 8) {
+            bload16(rsrc, vo, delta * 2u, dst);
+        }
+    };
+
+    // ---- fragment read addresses (bytes).  A operand = weights (rows = output channels), B operand = pixels.
+    int wa[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = wn * (NT * 32) + j * 32 + (lane & 31);
+        wa[j] = n * C16_ROWB + ((kh ^ ((n >> 1) & 7)) << 4);
+    }
+    int q0[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 32 + (lane & 31);
+        q0[i] = TAPS == 9 ? (m >> TWl) * HWd + (m & (TW - 1)) : m;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mfma_step = [&](int toff, int hb, int wb) {
+        // byte offsets into `lds`; the buffer bases are multiples of 128, so the k-step XOR (bits 5-6) commutes
+        int pb[MT], wo[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int q = q0[i] + toff;
+            pb[i] = q * C16_ROWB + ((kh ^ ((q >> 1) & 7)) << 4) + hb * G::HBYTES;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wo[j] = wa[j] + 2 * G::HBYTES + wb * G::WBYTES;
+        // explicit two-deep fragment pipeline: the 6 reads of k-step ks+1 are in flight under the 8 MFMAs of ks
+        half8 a[2][NT], b[2][MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[0][j] = *reinterpret_cast<const half8*>(lds + wo[j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[nxt][j] = *reinterpret_cast<const half8*>(lds + (wo[j] ^ ((ks + 1) << 5)));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) b[nxt][i] = *reinterpret_cast<const half8*>(lds + (pb[i] ^ ((ks + 1) << 5)));
+            }
+            __builtin_amdgcn_sched_barrier(0);          // reads of step ks+1 issue first, then the 8 MFMAs of ks cover them
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][j], b[cur][i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- K loop over (chunk, tap) steps of this split-K slice, then the fused 1x1 shortcut's chunks
+    const int nchunks = Cin / C16_KC;
+    const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
+    const int SC = d.SC0 + d.SC1, nsk = d.skip0 ? SC / C16_KC : 0;
+    const int s_begin = (int)((long)nsk * slice / p.ksplit), s_end = (int)((long)nsk * (slice + 1) / p.ksplit);
+    const int n_main = c_end - c_begin, n_skip = s_end - s_begin;
+    int hb = 0, wb = 0;
+#ifdef DDNM_P16_NO_MAIN
+    if (false) {
+#else
+    if (n_main > 0) {
+#endif
+        issue_halo(r_src, Cin, c_begin * C16_KC, 0);
+        issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)(c_begin * C16_KC), 0);
+    }
+#pragma unroll 1
+#ifdef DDNM_P16_NO_MAIN
+    for (int c = c_end; c < c_end; ++c) {
+#else
+    for (int c = c_begin; c < c_end; ++c) {
+#endif
+        const bool more = c + 1 < c_end;
+        int toff = 0, kx = 0;
+        // (rolled on purpose: unrolled, the compiler hoists 9 x 16 loop-invariant fragment addresses and spills)
+#pragma unroll 1
+        for (int tap = 0; tap < TAPS; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();           // this step's tiles have landed (every wave's), the other buffers are free
+            if (tap + 1 < TAPS) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
+            else if (more) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((c + 1) * C16_KC), wb ^ 1);
+            if (tap == 0 && more) issue_halo(r_src, Cin, (c + 1) * C16_KC, hb ^ 1);
+            mfma_step(toff, hb, wb);
+            wb ^= 1;
+            if (++kx == 3) { kx = 0; toff += HWd - 2; } else { ++toff; }
+        }
+        hb ^= 1;
+    }
+    if (TAPS == 9 && n_skip > 0) {
+        // fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's RAW
+        // input, read at the centre tap of its halo.  (Started after the main loop has drained: one pipeline
+        // bubble per launch, and the main loop carries no shortcut state.)
+        const __amdgpu_buffer_rsrc_t r_skw = make_rsrc(d.skip_weight, (unsigned)p.n_tiles * BN * SC * 2u);
+        const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(d.skip0, out_pix * d.SC0 * 2u);
+        const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(d.skip1 ? d.skip1 : d.skip0, out_pix * d.SC1 * 2u);
+        auto issue_skip = [&](int ch, int hbuf, int wbuf) {
+            const int cb = ch * C16_KC;
+            if (cb < d.SC0) issue_halo(r_sk0, d.SC0, cb, hbuf);
+            else issue_halo(r_sk1, d.SC1, cb - d.SC0, hbuf);
+            issue_w(r_skw, (unsigned)SC, (unsigned)cb, wbuf);
+        };
+        __syncthreads();
+        issue_skip(s_begin, hb, wb);
+#pragma unroll 1
+        for (int ch = s_begin; ch < s_end; ++ch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (ch + 1 < s_end) issue_skip(ch + 1, hb ^ 1, wb ^ 1);
+            mfma_step(HWd + 1, hb, wb);
+            wb ^= 1;
+            hb ^= 1;
+        }
+    }
+    __syncthreads();                   // all fragment reads done: LDS becomes the epilogue's staging area
+
+#ifdef DDNM_P16_NO_EPI
+    {   // probe: keep the accumulators live, write almost nothing
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 12345.678f) reinterpret_cast<_Float16*>(d.out)[tid] = (_Float16)t;
+        return;
+    }
+#endif
+    // ================================================================ epilogue
+    // D layout (32x32 MFMA, A = weights): lane -> pixel = lane & 31 of M tile i, channels
+    // wn*64 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
+    if constexpr (WNW == 1) {
+        // small-Cout output convolution (out.2 of the UNet, unet.py:627-631): fp32 NCHW, D rows = channels
+        // (r&3) + 8*(r>>2) + 4*kh, col = pixel; for a fixed channel 32 lanes store 32 consecutive x
+        float* outf = reinterpret_cast<float*>(d.out);
+        const int m = wm * 32 + (lane & 31);
+        const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (ch < d.Cout)
+                outf[(((size_t)img * d.Cout + ch) * d.H + oy) * d.W + ox] = acc[0][0][r] + (d.bias ? d.bias[ch] : 0.f);
+        }
+        return;
+    }
+    const int cbase = n_tile * C16_BN + wn * 64;
+    const bool wave_on = cbase < d.Cout;            // Cout % 64 == 0: a wave's 64-channel slice is all in or all out
+    if (p.ksplit > 1) {
+        float* ws = d.workspace + (size_t)slice * p.M * d.Cout;
+        if (!wave_on) return;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = (wm * MT + i) * 32 + (lane & 31);
+            int pix;
+            if (TAPS == 9) pix = (img * d.H + ty0 + (m >> TWl)) * d.W + tx0 + (m & (TW - 1));
+            else pix = m_tile * BM + m;
+            if (TAPS == 1 && pix >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int ch = cbase + j * 32 + 8 * rg + 4 * kh;
+                    f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+                    *reinterpret_cast<f32x4*>(ws + (size_t)pix * d.Cout + ch) = v;
+                }
+        }
+        return;
+    }
+    char* const stage = lds + wave * (MT * 32) * C16_EPITCH;
+    float* const stat_lds = reinterpret_cast<float*>(lds + 8 * (MT * 32) * C16_EPITCH);
+    if (wave_on) {
+        f32x4 bias4[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int ch = cbase + j * 32 + 8 * rg + 4 * kh;
+                bias4[j][rg] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 b4 = bias4[j][rg];
+                    char* dst = stage + (i * 32 + (lane & 31)) * C16_EPITCH + (j * 32 + 8 * rg + 4 * kh) * 2;
+                    half4 h = {(_Float16)(acc[i][j][4 * rg] + b4.x), (_Float16)(acc[i][j][4 * rg + 1] + b4.y),
+                               (_Float16)(acc[i][j][4 * rg + 2] + b4.z), (_Float16)(acc[i][j][4 * rg + 3] + b4.w)};
+                    *reinterpret_cast<half4*>(dst) = h;
+                }
+    }
+    // wave-local hand-off (each wave re-reads only its own staging region)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    constexpr int ITS = MT * 32 / 8;                 // lane -> (pixel = it*8 + lane/8, 8 channels = piece lane%8)
+    const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* const out = reinterpret_cast<_Float16*>(d.out);
+    const int chn = cbase + lpiece * 8;
+    int opix[ITS];
+    uint4 rv[ITS];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int m = wm * MT * 32 + it * 8 + lrow;
+        int pix, rpix;
+        if (TAPS == 9) {
+            const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
+            pix = (img * d.H + oy) * d.W + ox;
+            rpix = d.res_ups ? (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1) : pix;
+        } else {
+            pix = m_tile * BM + m;
+            rpix = pix;
+            if (pix >= p.M) pix = -1;
+        }
+        if (!wave_on) pix = -1;
+        opix[it] = pix;
+        rv[it] = uint4{0u, 0u, 0u, 0u};
+        if (res && pix >= 0) rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
+    }
+    float cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        half8 v = *reinterpret_cast<const half8*>(stage + (it * 8 + lrow) * C16_EPITCH + lpiece * 16);
+        if (res) {
+            const half8 r8 = __builtin_bit_cast(half8, rv[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)r8[e]);
+        }
+        if (opix[it] >= 0) {
+            *reinterpret_cast<half8*>(out + (size_t)opix[it] * d.Cout + chn) = v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                cs[e] += f;
+                cq[e] += f * f;
+            }
+        }
+    }
+    if (d.stats_out) {
+        // GroupNorm partials of the tensor just written (of the ROUNDED values the consumer will read):
+        // reduce over the 8 pixel rows of a wave (lanes with equal lane%8), then over the two pixel-halves (wm)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 8);  cq[e] += __shfl_xor(cq[e], 8);
+            cs[e] += __shfl_xor(cs[e], 16); cq[e] += __shfl_xor(cq[e], 16);
+            cs[e] += __shfl_xor(cs[e], 32); cq[e] += __shfl_xor(cq[e], 32);
+        }
+        if (lane < 8 && wave_on) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = wn * 64 + lane * 8 + e;
+                stat_lds[(wm * C16_BN + c) * 2 + 0] = cs[e];
+                stat_lds[(wm * C16_BN + c) * 2 + 1] = cq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < C16_BN) {
+            const int n = n_tile * C16_BN + tid;
+            if (n < d.Cout) {
+                const float a = stat_lds[tid * 2] + stat_lds[(C16_BN + tid) * 2];
+                const float q = stat_lds[tid * 2 + 1] + stat_lds[(C16_BN + tid) * 2 + 1];
+                *reinterpret_cast<float2*>(d.stats_out + ((size_t)m_tile * d.Cout + n) * 2) = float2{a, q};
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// split-K reduction: out(fp16) = round( sum_s ws[s] + bias + res ), + GroupNorm partials of the rounded values.
+// grid (B * tpi, ceil(Cout / 1024)); one workgroup per (image, pixel tile, 1024-channel slab); a thread owns one
+// float4 channel column and walks the tile's pixels (fixed order, no atomics).
+// =====================================================================================
+static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const Conv16Args p, int tpi) {
+    __shared__ f32x4 red[2][256];
+    const ddnm_conv16_desc& d = p.d;
+    const int cb = blockIdx.y * 1024;
+    const int cw = min(1024, d.Cout - cb);
+    const int c4n = cw >> 2;
+    const int rows = 256 / c4n > 0 ? 256 / c4n : 1, active = rows * c4n;
+    const int hw = d.H * d.W, P = hw / tpi;
+    const int b = blockIdx.x / tpi, t = blockIdx.x - b * tpi;
+    const size_t slab = (size_t)p.M * d.Cout;
+    const int tid = threadIdx.x;
+    const _Float16* res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* out = reinterpret_cast<_Float16*>(d.out);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (tid < active) {
+        const int c4 = tid % c4n, prow = tid / c4n, n = cb + c4 * 4;
+        f32x4 add = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) add = *reinterpret_cast<const f32x4*>(d.bias + n);
+        for (int pp = prow; pp < P; pp += rows) {
+            const int p2 = t * P + pp;
+            const size_t o = ((size_t)b * hw + p2) * d.Cout + n;
+            f32x4 v = *reinterpret_cast<const f32x4*>(d.workspace + o);
+            for (int k = 1; k < p.ksplit; ++k) v = v + *reinterpret_cast<const f32x4*>(d.workspace + o + k * slab);
+            v = v + add;
+            if (res) {
+                size_t ro = o;
+                if (d.res_ups) {
+                    const int oy = p2 / d.W, ox = p2 - oy * d.W;
+                    ro = (((size_t)b * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1)) * d.Cout + n;
+                }
+                const half4 r4 = *reinterpret_cast<const half4*>(res + ro);
+                v = v + f32x4{(float)r4.x, (float)r4.y, (float)r4.z, (float)r4.w};
+            }
+            const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<half4*>(out + o) = h;
+            const f32x4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+            s += f;
+            ss += f * f;
+        }
+    }
+    if (!d.stats_out) return;
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
+    if (tid < c4n) {
+        for (int r = 1; r < rows; ++r) { s += red[0][r * c4n + tid]; ss += red[1][r * c4n + tid]; }
+        float* o = d.stats_out + ((size_t)blockIdx.x * d.Cout + cb + tid * 4) * 2;
+        reinterpret_cast<f32x4*>(o)[0] = f32x4{s.x, ss.x, s.y, ss.y};
+        reinterpret_cast<f32x4*>(o)[1] = f32x4{s.z, ss.z, s.w, ss.w};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct Plan16 {
+    int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
+};
+
+static int splitk_tiles16(const ddnm_conv16_desc* d) {
+    const int hw = d->H * d->W;
+    int tpi = hw / 4 < 64 ? hw / 4 : 64;
+    if (tpi < 1) tpi = 1;
+    while (tpi > 1 && hw % tpi) --tpi;
+    return tpi;
+}
+
+static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
+    if (d->Cin <= 0 || d->Cin % C16_KC || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return false;
+    if (d->ksize != 1 && d->ksize != 3) return false;
+    pl->small = 0;
+    if (d->out_nchw_f32) {
+        // fp32 NCHW output with <= 32 channels: 256-pixel x 32-channel tiles, no residual / shortcut / statistics
+        if (d->ksize != 3 || d->Cout > 32 || d->ups || d->res || d->skip0 || d->stats_out) return false;
+        if (d->W % 32 || d->H % 8) return false;
+        pl->small = 1;
+        pl->taps = 9; pl->MT = 1; pl->TW = 32; pl->TW_log2 = 5; pl->tiles_x = d->W / 32;
+        pl->tiles_per_img = d->H * d->W / 256;
+        pl->m_tiles = d->B * pl->tiles_per_img;
+        pl->n_tiles = 1; pl->ksplit = 1; pl->stats_tiles = 0;
+        return true;
+    }
+    if (d->Cout % 64) return false;
+    const int hw = d->H * d->W;
+    const long M = (long)d->B * hw;
+    pl->taps = d->ksize == 3 ? 9 : 1;
+    pl->n_tiles = (d->Cout + C16_BN - 1) / C16_BN;
+    long tiles_of[5] = {0, 0, 0, 0, 0};
+    for (int mt = 2; mt <= 4; mt += 2) {
+        const int bm = 64 * mt;
+        if (pl->taps == 9) {
+            int tw = 32;
+            while (tw >= 16 && (d->W % tw || d->H % (bm / tw))) tw >>= 1;
+            if (tw < 16) continue;
+            tiles_of[mt] = (M / bm) * pl->n_tiles;
+        } else {
+            if (d->ups || d->skip0) return false;
+            tiles_of[mt] = ((M + bm - 1) / bm) * pl->n_tiles;
+        }
+    }
+    // the 256-pixel tile unless it cannot give most of the 256 CUs a workgroup and the 128-pixel tile can
+    int best_mt = tiles_of[4] > 0 ? 4 : (tiles_of[2] > 0 ? 2 : 0);
+    if (tiles_of[4] < 200 && tiles_of[2] > tiles_of[4]) best_mt = 2;
+    if (best_mt == 0) return false;
+    pl->MT = best_mt;
+    const int bm = 64 * best_mt;
+    if (pl->taps == 9) {
+        int tw = 32;
+        while (tw >= 16 && (d->W % tw || d->H % (bm / tw))) tw >>= 1;
+        pl->TW = tw;
+        pl->TW_log2 = tw == 32 ? 5 : 4;
+        pl->tiles_x = d->W / tw;
+        pl->tiles_per_img = hw / bm;
+        pl->m_tiles = (int)(M / bm);
+    } else {
+        pl->TW = 32; pl->TW_log2 = 5; pl->tiles_x = 0; pl->tiles_per_img = 0;
+        pl->m_tiles = (int)((M + bm - 1) / bm);
+    }
+    const long tiles = (long)pl->m_tiles * pl->n_tiles;
+    const int nchunks = d->Cin / C16_KC;
+    int ks = 1;
+    if (tiles < 160) {
+        ks = (int)((320 + tiles - 1) / tiles);
+        const int steps = nchunks;                 // keep >= 2 chunks per slice
+        if (ks > steps / 2) ks = steps / 2 > 0 ? steps / 2 : 1;
+        if (ks > 32) ks = 32;
+    }
+    pl->ksplit = ks;
+    if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
+    else pl->stats_tiles = (pl->taps == 9 || hw % bm == 0) ? hw / bm : 0;
+    return true;
+}
+
+extern "C" int ddnm_conv16_supported(const ddnm_conv16_desc* d) {
+    Plan16 pl;
+    return d && plan16(d, &pl) ? 1 : 0;
+}
+
+extern "C" int64_t ddnm_conv16_workspace_floats(const ddnm_conv16_desc* d) {
+    Plan16 pl;
+    if (!d || !plan16(d, &pl)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->B * d->H * d->W * d->Cout : 0;
+}
+
+extern "C" int ddnm_conv16_stats_tiles(const ddnm_conv16_desc* d) {
+    Plan16 pl;
+    if (!d || !plan16(d, &pl)) return DDNM_E_SHAPE;
+    return pl.stats_tiles;
+}
+
+extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
+    if (!d || !d->src || !d->weight || !d->out) return DDNM_E_BADARG;
+    Plan16 pl;
+    if (!plan16(d, &pl)) return DDNM_E_SHAPE;
+    if (d->ups && ((d->H | d->W) & 1)) return DDNM_E_SHAPE;
+    if (d->res_ups && ((d->H | d->W) & 1)) return DDNM_E_SHAPE;
+    if (d->skip0) {
+        if (pl.taps != 9 || d->ups || !d->skip_weight || d->SC0 <= 0 || d->SC0 % C16_KC || d->SC1 % C16_KC ||
+            (d->SC1 > 0 && !d->skip1))
+            return DDNM_E_SHAPE;
+    }
+    if (d->stats_out && pl.stats_tiles <= 0) return DDNM_E_SHAPE;
+    if (pl.ksplit > 1) {
+        const int64_t need = (int64_t)pl.ksplit * d->B * d->H * d->W * d->Cout;
+        if (!d->workspace || d->workspace_floats < need) return DDNM_E_BADARG;
+        if (d->Cout % 4) return DDNM_E_SHAPE;
+    }
+    Conv16Args p;
+    p.d = *d;
+    p.TW = pl.TW; p.TW_log2 = pl.TW_log2; p.tiles_x = pl.tiles_x; p.tiles_per_img = pl.tiles_per_img;
+    p.m_tiles = pl.m_tiles; p.n_tiles = pl.n_tiles; p.ksplit = pl.ksplit;
+    p.M = d->B * d->H * d->W;
+    p.Hs = d->ups ? d->H / 2 : d->H;
+    p.Ws = d->ups ? d->W / 2 : d->W;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(pl.m_tiles * pl.n_tiles, pl.ksplit);
+    if (pl.small) {
+        DDNM_LAUNCH((conv16_kernel<9, 1, 1>), grid, dim3(512), 0, s, p);
+    } else if (pl.taps == 9) {
+        if (pl.MT == 4) { DDNM_LAUNCH((conv16_kernel<9, 4, 4>), grid, dim3(512), 0, s, p); }
+        else { DDNM_LAUNCH((conv16_kernel<9, 2, 4>), grid, dim3(512), 0, s, p); }
+    } else {
+        if (pl.MT == 4) { DDNM_LAUNCH((conv16_kernel<1, 4, 4>), grid, dim3(512), 0, s, p); }
+        else { DDNM_LAUNCH((conv16_kernel<1, 2, 4>), grid, dim3(512), 0, s, p); }
+    }
+    if (pl.ksplit > 1) {
+        const int tpi = pl.stats_tiles;
+        DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 1023) / 1024), dim3(256), 0, s, p, tpi);
+    }
+    return 0;
+}

@@ -16,11 +16,14 @@ Kernel mapping (ddnm_amd/csrc), activations NHWC fp32 in HBM:
     (channel = head*192 + {q,k,v}*64 + c), QK^T and PV as batched MFMA GEMMs, fp32 softmax;
   * all `emb_layers` Linears -> ONE launch per step.
 
-Precision: fp32 on `v_mfma_f32_32x32x2_f32` by default; after `convert_to_fp16()` (what the runner calls for
-`use_fp16: true`, diffusion.py:145-146) the 3x3 convolutions of the torso run on fp16 MFMA operands with fp32
-accumulation (`v_mfma_f32_32x32x16_f16`, csrc/conv_igemm_f16.hip) while GroupNorm, softmax, embeddings and every
-tensor in HBM stay fp32 -- never less precise than the reference's fp16 torso (fp16_util.py:15-22).
+Precision: fp32 on `v_mfma_f32_32x32x2_f32` by default.  After `convert_to_fp16()` (what the runner calls for
+`use_fp16: true`, diffusion.py:145-146) the torso runs the fp16-ACTIVATION path (`_forward16`): every activation
+in HBM is fp16 NHWC like the reference's `h.type(self.dtype)` tensors (unet.py:655-663), convolutions are
+`ddnm_conv16` (fp16 MFMA operands, fp32 accumulation, csrc/conv16.hip), attention is the fused `ddnm_attn16_d64`,
+GroupNorm statistics / softmax / embeddings stay fp32 (fp16_util.py:15-22, nn.py:17-19) and the output convolution
+returns fp32 NCHW.  (`DDNM_ADM_GEN1=1` selects the first-generation path: fp32 activations, fp16 MFMA operands.)
 """
+import os
 import math
 from collections import OrderedDict
 
@@ -140,6 +143,7 @@ class UNetModel:
         self.use_fp16 = True
         if self.w is not None:
             self._pack_f16()
+            self._pack_h16()
         return self
 
     def convert_to_fp32(self):
@@ -153,6 +157,22 @@ class UNetModel:
         for key, raw in self._raw.items():
             if key.endswith(".pad64") and key + ".f16" not in self.w:
                 self.w[key + ".f16"] = ops.pack_conv_weight_f16(raw, cin_pad=CIN_PAD_F16)
+
+    def _pack_h16(self):
+        """fp16 (O,ky,kx,I) weights of the fp16-activation path, Cout padded to 256 rows (ops.pack_conv_weight16)."""
+        w = self.w
+        if "h16.ready" in w:
+            return
+        for key, raw in self._raw_all.items():
+            if key.endswith("input_blocks.0.0.weight"):
+                w[key + ".h16"] = ops.pack_conv_weight16(raw, cin_pad=CIN_PAD_F16)
+            elif key.endswith(".skip_connection.weight"):
+                p16 = ops.pack_conv_weight16(raw)
+                w[key + ".h16"] = p16                                              # as a 1x1 convolution
+                w[key + ".h16.flat"] = p16.reshape(p16.shape[0], -1).contiguous()   # as the fused shortcut's [Cout][Cin]
+            else:
+                w[key + ".h16"] = ops.pack_conv_weight16(raw)
+        w["h16.ready"] = True
 
     def parameters(self):
         return iter(())
@@ -207,6 +227,7 @@ class UNetModel:
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731 (fp16 ckpts upcast)
         w = {}
         self._raw, self._f16_keys = {}, []
+        self._raw_all = {}
         for k in ("time_embed.0", "time_embed.2"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
         if self.num_classes is not None:
@@ -218,6 +239,7 @@ class UNetModel:
                 if L[0] == "conv":
                     w[n + ".weight"] = ops.pack_conv_weight(g(n + ".weight"), cin_pad=CIN_PAD)
                     w[n + ".bias"] = g(n + ".bias")
+                    self._raw_all[n + ".weight"] = g(n + ".weight")
                     if L[2] % 128 == 0:          # fp16 mode: the 3 input channels are zero-padded to one 64-channel chunk
                         self._raw[n + ".weight.pad64"] = g(n + ".weight")
                 elif L[0] == "res":
@@ -227,6 +249,7 @@ class UNetModel:
                         raw = g(f"{n}.{conv}.weight")
                         w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
                         w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
+                        self._raw_all[f"{n}.{conv}.weight"] = raw
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
                             self._raw[f"{n}.{conv}.weight"] = raw
                             self._f16_keys.append(f"{n}.{conv}.weight")
@@ -234,6 +257,7 @@ class UNetModel:
                     fb.append(g(n + ".emb_layers.1.bias"))
                     if L[1] != L[2]:
                         raw = g(n + ".skip_connection.weight")
+                        self._raw_all[n + ".skip_connection.weight"] = raw
                         w[n + ".skip_connection.weight"] = ops.pack_conv_weight(raw)
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
                             self._raw[n + ".skip_connection.weight"] = raw
@@ -246,6 +270,7 @@ class UNetModel:
                     w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
                     for conv in ("qkv", "proj_out"):                     # Conv1d(k=1) == 1x1 convolution
                         raw = g(f"{n}.{conv}.weight").unsqueeze(-1)
+                        self._raw_all[f"{n}.{conv}.weight"] = raw
                         w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
                         w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
@@ -256,12 +281,14 @@ class UNetModel:
         w["out.0.weight"], w["out.0.bias"] = g("out.0.weight"), g("out.0.bias")
         w["out.2.weight"] = ops.pack_conv_weight(g("out.2.weight"))
         w["out.2.bias"] = g("out.2.bias")
+        self._raw_all["out.2.weight"] = g("out.2.weight")
         half = self.model_channels // 2
         w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         self.w = w
         self._ws = None
         if self.use_fp16:
             self._pack_f16()
+            self._pack_h16()
         return self
 
     def _w16(self, key):
@@ -355,6 +382,96 @@ class UNetModel:
                 h = self._attn(n, h)
         return h
 
+    # ------------------------------------------------------------------ fp16-activation forward (csrc/conv16.hip)
+    def _conv3x3_16(self, key, cout, x0, x1, gn, silu=True, **kw):
+        """3x3 convolution of act(concat(x0, x1)): activated operand written once (ops.gn_apply16), then ddnm_conv16;
+        images too small for a pixel tile (8x8) go through im2col + one GEMM with K = 9*Cin."""
+        w16 = self.w[key + ".h16"]
+        B, H, W, _ = x0.t.shape
+        cin = x0.t.shape[3] + (0 if x1 is None else x1.t.shape[3])
+        ups = kw.get("ups", False)
+        Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+        if ops.conv16_supported(B, Ho, Wo, cin, cout, 3, ups=ups):
+            a = x0.t if (gn is None and x1 is None) else ops.gn_apply16(x0, x1, gn, silu)
+            return ops.conv16(a, w16, cout, 3, **kw)
+        assert not ups and kw.get("skip") is None
+        col = ops.im2col16(x0, x1, gn, silu)
+        return ops.conv16(col, w16.reshape(w16.shape[0], 1, -1), cout, 1, **kw)
+
+    def _res16(self, n, L, x0, x1, film_all):
+        w = self.w
+        cin, cout, mode = L[1], L[2], L[3]
+        film = film_all[:, self._film_off[n]:]
+        gn1 = self._gn(x0, x1, n + ".in_layers.0")
+        b1, b2 = w[n + ".in_layers.2.bias"], w[n + ".out_layers.3.bias"]
+        k1, k2 = n + ".in_layers.2.weight", n + ".out_layers.3.weight"
+        if mode == "down":          # AvgPool2d on both branches (unet.py:237-242)
+            hp = ops.Act(ops.gn_apply16(x0, None, gn1, True, pool=True))
+            xs = ops.gn_apply16(x0, None, None, False, pool=True)
+            h = self._conv3x3_16(k1, cout, hp, None, None, bias=b1)
+            gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs)
+        if mode == "up":            # nearest x2 on both branches: operand through `ups`, residual through `res_ups`
+            h = self._conv3x3_16(k1, cout, x0, None, gn1, bias=b1, ups=True)
+            gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0, res_ups=True)
+        h = self._conv3x3_16(k1, cout, x0, x1, gn1, bias=b1)
+        gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
+        if cin == cout:
+            assert x1 is None
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0)
+        B, H, W, _ = h.t.shape
+        if ops.conv16_supported(B, H, W, cout, cout, 3):      # 1x1 shortcut fused as extra K chunks over the raw input
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=w[n + ".out_plus_skip.bias"], skip=(x0, x1),
+                                    skip_weight=w[n + ".skip_connection.weight.h16.flat"])
+        raw = x0.t if x1 is None else ops.gn_apply16(x0, x1, None, False)      # materialised concat of the raw tensors
+        xs = ops.conv16(raw, w[n + ".skip_connection.weight.h16"], cout, 1, bias=w[n + ".skip_connection.bias"],
+                        emit_stats=False)
+        return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs)
+
+    def _attn16(self, n, x):
+        w = self.w
+        C = x.t.shape[3]
+        hc = self.num_head_channels if self.num_head_channels != -1 else C // self.num_heads
+        if hc != 64:
+            raise NotImplementedError("the fused attention kernel is built for 64-channel heads (all DDNM configs)")
+        gn = self._gn(x, None, n + ".norm")
+        a = ops.gn_apply16(x, None, gn, False)
+        qkv = ops.conv16(a, w[n + ".qkv.weight.h16"], 3 * C, 1, bias=w[n + ".qkv.bias"], emit_stats=False)
+        o = ops.attn16(qkv.t, C)
+        return ops.conv16(o, w[n + ".proj_out.weight.h16"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+
+    def _run16(self, prefix, layers, h, skip, film_all):
+        for j, L in enumerate(layers):
+            n = f"{prefix}.{j}"
+            if L[0] == "res":
+                h = self._res16(n, L, h, skip if j == 0 else None, film_all)
+            else:
+                h = self._attn16(n, h)
+        return h
+
+    def _forward16(self, x, film_all):
+        w = self.w
+        n0 = "input_blocks.0.0"
+        h = ops.nchw_to_nhwc16(x.float().contiguous(), CIN_PAD_F16)
+        h = ops.conv16(h, w[n0 + ".weight.h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
+        hs = [h]
+        for i, layers in enumerate(self.input_blocks):
+            if i == 0:
+                continue
+            h = self._run16(f"input_blocks.{i}", layers, h, None, film_all)
+            hs.append(h)
+        h = self._run16("middle_block", self.middle_block, h, None, film_all)
+        for i, layers in enumerate(self.output_blocks):
+            h = self._run16(f"output_blocks.{i}", layers, h, hs.pop(), film_all)
+        gn = self._gn(h, None, "out.0")
+        a = ops.gn_apply16(h, None, gn, True)
+        B, H, W, _ = a.shape
+        if W % 32 == 0 and H % 8 == 0:
+            return ops.conv16_out(a, w["out.2.weight.h16"], self.out_channels, bias=w["out.2.bias"])
+        # images narrower than one 32-pixel output tile (reduced test nets): the exact-fp32 kernel on the fp16 operand
+        return ops.conv2d(a.float(), w["out.2.weight"], self.out_channels, 3, bias=w["out.2.bias"], out_nchw=True)
+
     def forward(self, x, timesteps, y=None):
         if self.w is None:
             raise RuntimeError("load_state_dict() must be called before forward()")
@@ -371,6 +488,8 @@ class UNetModel:
             assert y.shape == (B,)
             ops.embedding_add_(emb, w["label_emb.weight"], y)
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
+        if self.use_fp16 and os.environ.get("DDNM_ADM_GEN1") != "1":
+            return self._forward16(x, film_all)
 
         n0 = "input_blocks.0.0"
         H, W = x.shape[2], x.shape[3]

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, GemmDesc, StepScalars, check
+from ._lib import Conv16Desc, ConvDesc, GemmDesc, StepScalars, check
 
 
 def _p(t):
@@ -252,6 +252,169 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     return out
 
 
+# ----------------------------------------------------------------------------- fp16-activation path (csrc/conv16.hip)
+CONV16_COUT_ALIGN = 256
+
+
+def _f16c(t, name):
+    if t.dtype != torch.float16 or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError(f"{name}: expected a contiguous float16 device tensor, got {t.dtype} "
+                         f"contiguous={t.is_contiguous()} device={t.device}")
+    return t
+
+
+def pack_conv_weight16(w, cin_pad=None):
+    """OIHW (or OI for Conv1d k=1 / Linear-like) -> fp16 (O, ky, kx, I) with Cout padded to 256, Cin to `cin_pad`."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    cout, cin, kh, kw = w.shape
+    cin_pad = cin if cin_pad is None else cin_pad
+    cout_pad = (cout + CONV16_COUT_ALIGN - 1) // CONV16_COUT_ALIGN * CONV16_COUT_ALIGN
+    out = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
+    out[:cout, :, :cin] = w.float().permute(0, 2, 3, 1).reshape(cout, kh * kw, cin).to(torch.float16)
+    return out.contiguous()
+
+
+def _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups):
+    B = src.shape[0]
+    d = Conv16Desc()
+    d.src, d.weight, d.bias, d.res = _p(_f16c(src, "src")), _p(_f16c(weight, "weight")), _p(bias), _p(res)
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, W, src.shape[-1], cout, ksize
+    d.ups, d.res_ups = int(ups), int(res_ups)
+    if skip is not None:
+        s0, s1 = skip
+        d.skip0, d.skip1, d.skip_weight = _p(_f16c(s0, "skip0")), _p(s1), _p(_f16c(skip_weight, "skip_weight"))
+        d.SC0, d.SC1 = s0.shape[-1], (0 if s1 is None else s1.shape[-1])
+    return d
+
+
+def conv16_supported(B, H, W, cin, cout, ksize, ups=False):
+    d = Conv16Desc()
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.ups = B, H, W, cin, cout, ksize, int(ups)
+    return _lib.lib().ddnm_conv16_supported(ctypes.byref(d)) == 1
+
+
+def conv16(src, weight, cout, ksize, *, bias=None, res=None, res_ups=False, ups=False, skip=None, skip_weight=None,
+           emit_stats=True, out=None):
+    """fp16 NHWC convolution of the `use_fp16` torso (include/ddnm_hip.h::ddnm_conv16_desc): `src` is the already
+    activated fp16 operand [B,Hs,Ws,Cin]; returns an `Act` whose tensor is fp16 [B,H,W,cout] and whose GroupNorm
+    partials (when the launch can emit them) describe exactly those rounded values."""
+    src = src.t if isinstance(src, Act) else src
+    res = res.t if isinstance(res, Act) else res
+    B, Hs, Ws, _ = src.shape
+    H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    if skip is not None:
+        skip = tuple(None if s is None else (s.t if isinstance(s, Act) else s) for s in skip)
+    d = _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups)
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(B, H, W, cout, dtype=torch.float16, device=src.device)
+    d.out = _p(_f16c(out, "out"))
+    stats, tiles = None, 0
+    if emit_stats:
+        tiles = L.ddnm_conv16_stats_tiles(ctypes.byref(d))
+        if tiles < 0:
+            check(tiles, "ddnm_conv16_stats_tiles")
+        if tiles > 0:
+            stats = torch.empty(B * tiles * cout * 2, dtype=torch.float32, device=src.device)
+            d.stats_out = stats.data_ptr()
+    need = L.ddnm_conv16_workspace_floats(ctypes.byref(d))
+    if need < 0:
+        check(int(need), "ddnm_conv16_workspace_floats")
+    if need > 0:
+        ws = _conv_workspace(src.device, need)
+        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
+    if _timer is None:
+        check(L.ddnm_conv16(ctypes.byref(d), _stream()), "ddnm_conv16")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(L.ddnm_conv16(ctypes.byref(d), _stream()), "ddnm_conv16")
+        e1.record()
+        flops = 2.0 * B * H * W * cout * (ksize * ksize * d.Cin + d.SC0 + d.SC1)
+        _timer.records.append((f"conv16<{ksize}x{ksize}>", flops, e0, e1))
+        _timer.shapes.append((B, H, W, d.Cin, cout, ksize, 1, int(ups), d.SC0 + d.SC1, False, res is not None))
+    return Act(out, stats, tiles)
+
+
+def conv16_out(src, weight, cout, bias=None):
+    """The network's output convolution on the fp16 path: 3x3, cout <= 32, fp32 NCHW result (unet.py:627-631,664)."""
+    src = src.t if isinstance(src, Act) else src
+    B, H, W, _ = src.shape
+    d = _conv16_desc(src, weight, cout, 3, H, W, False, None, None, bias, None, False)
+    d.out_nchw_f32 = 1
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=src.device)
+    d.out = out.data_ptr()
+    if _timer is None:
+        check(_lib.lib().ddnm_conv16(ctypes.byref(d), _stream()), "ddnm_conv16(out)")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().ddnm_conv16(ctypes.byref(d), _stream()), "ddnm_conv16(out)")
+        e1.record()
+        _timer.records.append(("conv16<out>", 2.0 * B * H * W * cout * 9 * d.Cin, e0, e1))
+        _timer.shapes.append((B, H, W, d.Cin, cout, 3, 1, 0, 0, False, False))
+    return out
+
+
+def gn_apply16(src0, src1, gn, silu, pool=False):
+    """fp16 operand of the next convolution: act(concat_c(src0, src1) * scale + shift), optionally 2x2 average-pooled
+    (gn=None: plain concat / pooling of the raw tensors)."""
+    src0 = src0.t if isinstance(src0, Act) else src0
+    src1 = src1.t if isinstance(src1, Act) else src1
+    B, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    out = torch.empty(B, Ho, Wo, C0 + C1, dtype=torch.float16, device=src0.device)
+    sc, sh = (None, None) if gn is None else gn
+    check(_lib.lib().ddnm_gn_apply_h16(_p(_f16c(src0, "src0")), _p(src1), _p(sc), _p(sh), _p(out), B, H, W, C0, C1,
+                                       int(silu), int(pool), _stream()), "ddnm_gn_apply_h16")
+    return out
+
+
+def im2col16(src0, src1, gn, silu):
+    src0 = src0.t if isinstance(src0, Act) else src0
+    src1 = src1.t if isinstance(src1, Act) else src1
+    B, H, W, C0 = src0.shape
+    C1 = 0 if src1 is None else src1.shape[3]
+    out = torch.empty(B, H, W, 9 * (C0 + C1), dtype=torch.float16, device=src0.device)
+    sc, sh = (None, None) if gn is None else gn
+    check(_lib.lib().ddnm_im2col3x3_h16(_p(_f16c(src0, "src0")), _p(src1), _p(sc), _p(sh), _p(out), B, H, W, C0, C1,
+                                        int(silu), _stream()), "ddnm_im2col3x3_h16")
+    return out
+
+
+def nchw_to_nhwc16(x, cpad):
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, cpad, dtype=torch.float16, device=x.device)
+    check(_lib.lib().ddnm_nchw_to_nhwc_h16(_p(_f32c(x, "x")), _p(out), B, C, H * W, cpad, _stream()),
+          "ddnm_nchw_to_nhwc_h16")
+    return out
+
+
+def gn_stats16(t):
+    """GroupNorm partials of an fp16 NHWC tensor whose producer could not emit them."""
+    B, H, W, C = t.shape
+    hw = H * W
+    tiles = 1
+    for cand in (64, 32, 16, 8, 4, 2):
+        if hw % cand == 0 and hw // cand >= 4:
+            tiles = cand
+            break
+    stats = torch.empty(B * tiles * C * 2, dtype=torch.float32, device=t.device)
+    check(_lib.lib().ddnm_gn_stats_h16(_p(_f16c(t, "t")), _p(stats), B, hw, C, tiles, _stream()), "ddnm_gn_stats_h16")
+    return Act(t, stats, tiles)
+
+
+def attn16(qkv, C):
+    """Fused multi-head attention (head dim 64) over the legacy-ordered fp16 qkv tensor [B,H,W,3C] -> [B,H,W,C]."""
+    B, H, W, C3 = qkv.shape
+    assert C3 == 3 * C
+    out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
+    check(_lib.lib().ddnm_attn16_d64(_p(_f16c(qkv, "qkv")), _p(out), B, H * W, C, _stream()), "ddnm_attn16_d64")
+    return out
+
+
 # ----------------------------------------------------------------------------- GroupNorm
 class GroupNormWorkspace:
     """Scratch shared by every GroupNorm of a forward pass (stream order makes reuse safe)."""
@@ -277,6 +440,11 @@ def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, fi
     # keep: optional dict that receives private copies of (scale, shift, mean_rstd) for a backward pass
     a0 = src0 if isinstance(src0, Act) else Act(src0)
     a1 = None if src1 is None else (src1 if isinstance(src1, Act) else Act(src1))
+    if a0.t.dtype == torch.float16:          # fp16-activation path: statistics always come as tile partials
+        if a0.stats is None:
+            a0 = gn_stats16(a0.t)
+        if a1 is not None and a1.stats is None:
+            a1 = gn_stats16(a1.t)
     src0, src1 = a0.t, (None if a1 is None else a1.t)
     B, H, W, C0 = src0.shape
     C1 = 0 if src1 is None else src1.shape[3]

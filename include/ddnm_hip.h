@@ -117,6 +117,71 @@ int64_t ddnm_conv1x1_f16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv1x1_f16_stats_tiles(const ddnm_conv_desc* d);
 
 /* ------------------------------------------------------------------------- *
+ * fp16-ACTIVATION path of the `use_fp16` torso (guided_diffusion/unet.py:619-625,655-663; fp16_util.py:15-22):
+ * every tensor in HBM is fp16 NHWC, like the reference's `h.type(self.dtype)` tensors; accumulation, GroupNorm
+ * statistics, softmax stay fp32.
+ *
+ * ddnm_conv16: 3x3 (stride 1, pad 1) or 1x1 convolution, v_mfma_f32_32x32x16_f16, 256 x 256 tiles staged by
+ * LDS-DMA (csrc/conv16.hip).  Replaces the nn.Conv2d / Conv1d(k=1) of ResBlock / AttentionBlock
+ * (unet.py:196-222,283-308) with, fused: nearest x2 upsample of the operand (ups; unet.py:104-109), the 1x1
+ * skip_connection as extra K chunks (unet.py:222,256), bias, residual add (through a nearest x2 upsample for
+ * `up=True` blocks) and the GroupNorm partials of the output.
+ *   out[b,y,x,n] = fp16( bias[n] + res[b,y,x,n] + sum W[n,ky,kx,c] * src[b, y+ky-1, x+kx-1, c]
+ *                        + sum W_skip[n,c] * concat_c(skip0, skip1)[b,y,x,c] )
+ * `src` is ALREADY normalised / activated (ddnm_gn_apply_h16), zero padded by the kernel.
+ * Needs Cin % 64 == 0, Cout % 64 == 0; 3x3: W % 16 == 0 and H*W % 128 == 0 (smaller images: ddnm_im2col3x3_h16 +
+ * ksize 1).  ksize 1 treats src as a flat [B*H*W][Cin] matrix (any row count).
+ * ------------------------------------------------------------------------- */
+typedef struct ddnm_conv16_desc {
+    const void* src;          /* fp16 NHWC [B][Hs][Ws][Cin]; Hs = H/2 when ups */
+    const void* weight;       /* fp16 packed [ceil(Cout/256)*256][ksize*ksize][Cin] (O,ky,kx,I) */
+    const float* bias;        /* [Cout] or NULL */
+    const void* res;          /* fp16 NHWC [B][H][W][Cout] ([B][H/2][W/2][Cout] when res_ups) or NULL */
+    const void* skip0;        /* fp16 NHWC [B][H][W][SC0] raw shortcut input or NULL (3x3 only) */
+    const void* skip1;        /* fp16 NHWC [B][H][W][SC1] or NULL */
+    const void* skip_weight;  /* fp16 [ceil(Cout/256)*256][SC0+SC1] */
+    void* out;                /* fp16 NHWC [B][H][W][Cout]; fp32 NCHW [B][Cout][H][W] when out_nchw_f32 */
+    float* stats_out;         /* optional [B*tiles][Cout][2] GroupNorm partials of the ROUNDED output,
+                                 tiles = ddnm_conv16_stats_tiles(d); feeds ddnm_gn_finalize_tiles_f32 */
+    float* workspace;         /* split-K slabs, ddnm_conv16_workspace_floats(d) floats (0: not needed) */
+    int64_t workspace_floats;
+    int32_t B, H, W;          /* OUTPUT size (= input size; the operand is H/2 x W/2 when ups) */
+    int32_t Cin, Cout;
+    int32_t ksize;            /* 1 or 3 */
+    int32_t ups, res_ups;
+    int32_t SC0, SC1;
+    int32_t out_nchw_f32;     /* 1: the network's output convolution (unet.py:627-631, `.type(x.dtype)` :664): 3x3,
+                                 Cout <= 32 (weight packed to 32 rows or more), fp32 NCHW result, no res / skip / stats */
+    int32_t reserved;
+} ddnm_conv16_desc;
+
+int ddnm_conv16(const ddnm_conv16_desc* d, void* stream);
+int ddnm_conv16_supported(const ddnm_conv16_desc* d);
+int64_t ddnm_conv16_workspace_floats(const ddnm_conv16_desc* d);
+int ddnm_conv16_stats_tiles(const ddnm_conv16_desc* d);   /* 0: this launch cannot emit stats_out */
+
+/* HBM-bound stages of the fp16-activation path (csrc/act16.hip), all fp16 NHWC:
+ *   gn_apply:  out = fp16(act(concat_c(src0, src1) * scale[b,c] + shift[b,c])), act = swish when silu (scale NULL:
+ *              plain copy / concat); pool = 1 additionally averages 2x2 pixels (AvgPool2d of `down=True` ResBlocks,
+ *              guided_diffusion/unet.py:237-242): out is [B][H/2][W/2][C].  Replaces GroupNorm32 + SiLU
+ *              (nn.py:12-19; unet.py:196-205,226-230) and torch.cat([h, hs.pop()], 1) (unet.py:661).
+ *   im2col:    col[(b*H*W + p)][tap*C + c] of a 3x3 / pad 1 convolution input with the same prologue (8x8 level).
+ *   nchw_to_nhwc: fp32 NCHW [B][C][HW] -> fp16 NHWC [B][HW][cpad], zero padded (`x.type(self.dtype)`, unet.py:655).
+ *   gn_stats:  per-(pixel tile, channel) sum / sum of squares of an fp16 tensor, layout of `stats_out`. */
+int ddnm_gn_apply_h16(const void* src0, const void* src1, const float* scale, const float* shift, void* out, int32_t B,
+                      int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t silu, int32_t pool, void* stream);
+int ddnm_im2col3x3_h16(const void* src0, const void* src1, const float* scale, const float* shift, void* out, int32_t B,
+                       int32_t H, int32_t W, int32_t C0, int32_t C1, int32_t silu, void* stream);
+int ddnm_nchw_to_nhwc_h16(const float* x, void* out, int32_t B, int32_t C, int32_t HW, int32_t cpad, void* stream);
+int ddnm_gn_stats_h16(const void* src, float* stats, int32_t B, int32_t HW, int32_t C, int32_t tiles, void* stream);
+
+/* Fused multi-head self-attention, head dim 64 (QKVAttentionLegacy, guided_diffusion/unet.py:328-354 inside
+ * AttentionBlock :259-308): out[b,t,h*64+d] = sum_s softmax_s(q_t . k_s / 8) v_s[d] with
+ * qkv fp16 [B][T][3C] laid out head-major (channel = h*192 + {q,k,v}*64 + d), out fp16 [B][T][C]; fp32 softmax,
+ * probabilities rounded to fp16 like `.type(weight.dtype)`; no [T][T] tensor in HBM.  T % 64 == 0, C % 64 == 0. */
+int ddnm_attn16_d64(const void* qkv, void* out, int32_t B, int32_t T, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
  * Replaces torch.nn.GroupNorm(32, C, eps) (models.py:32-33; guided_diffusion/nn.py:17-19).
  *   stats:    partial (sum, sumsq) per (b, chunk, group) in double, deterministic order

@@ -127,3 +127,30 @@ def simplified_net(res):
         return celeba_net("small")
     cfg = weights.celeba_config(ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=1, attn_resolutions=(16,), resolution=res)
     return cfg, weights.celeba_state_dict(cfg, SEED)
+
+
+# ---- full BASELINE configurations (tests/golden/full_*.npz) ---------------------------------
+# c2b8: configs[1] itself (celeba_hq Model, sr_bicubic 4x, B=8, T=100);  c3 / c4 / c5: one image of configs[2..4] on
+# the full 552 M-parameter ADM net (colorization T=100; inpainting with exp/inp_masks/mask.npy, travel l=10 r=3 =
+# 460 loop iterations / 280 NFE; class-conditional + classifier guidance + cs_walshhadamard 0.25).
+FULL_CASES = {
+    "c2b8": dict(net="celeba", deg="sr_bicubic", batch=8, T=100, travel=(1, 1), class_cond=False, record=(10, 50, 90)),
+    "c3": dict(net="adm", deg="colorization", batch=1, T=100, travel=(1, 1), class_cond=False, record=(10, 50, 90)),
+    "c4": dict(net="adm", deg="inpainting", batch=1, T=100, travel=(10, 3), class_cond=False, record=(9, 229, 449)),
+    "c5": dict(net="adm", deg="cs_walshhadamard", batch=1, T=100, travel=(1, 1), class_cond=True, record=(10, 50, 90)),
+}
+
+
+def full_case(name):
+    """(case dict, cfg, state_dict, x_orig, x_T, tape) of one full BASELINE configuration."""
+    c = FULL_CASES[name]
+    if c["net"] == "celeba":
+        cfg, sd = celeba_net("full")
+    else:
+        cfg = weights.adm_config(class_cond=c["class_cond"])
+        sd = weights.adm_state_dict(cfg, SEED)
+    tt = cfg.time_travel
+    tt.T_sampling, tt.travel_length, tt.travel_repeat = c["T"], c["travel"][0], c["travel"][1]
+    n_it = len(schedule.jump_times(c["T"], *c["travel"])) - 1
+    x_orig, x_T, tape = sampler_case(cfg, c["batch"], n_it)
+    return c, cfg, sd, x_orig, x_T, tape

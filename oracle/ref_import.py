@@ -105,13 +105,15 @@ def cuda_is_cpu():
 
 
 @contextlib.contextmanager
-def noise_tape(tape):
+def noise_tape(tape, on_call=None):
     """Shim (iii): every `torch.randn_like(x)` pops the next tensor of `tape`.
 
-    `tape` is a list of tensors shaped like x; an exhausted tape raises.
+    `tape` is a list of tensors shaped like x; an exhausted tape raises.  `on_call(k, x)` (optional) sees the
+    argument of the k-th call -- in `ddnm_diffusion` that is the current x0|t (svd_ddnm.py:65,74).
     """
     it = iter(tape)
     orig = torch.randn_like
+    count = [0]
 
     def randn_like(x, *a, **k):
         try:
@@ -119,6 +121,9 @@ def noise_tape(tape):
         except StopIteration:
             raise RuntimeError("noise tape exhausted")
         assert n.shape == x.shape, (n.shape, x.shape)
+        if on_call is not None:
+            on_call(count[0], x)
+        count[0] += 1
         return n.to(dtype=x.dtype, device=x.device)
 
     torch.randn_like = randn_like

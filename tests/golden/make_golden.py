@@ -335,9 +335,78 @@ def make_adm():
     np.savez_compressed(os.path.join(HERE, "adm_forward.npz"), **out)
 
 
+def make_full(names):
+    """--full-adm / --full-c2b8: the FULL BASELINE configurations through the real reference loop
+    (functions/svd_ddnm.py:19-78), operators built as guided_diffusion/diffusion.py:451-523 builds them, fp32
+    models from the reference constructors (`Model`, `create_model`, `create_classifier`), `cond_fn` restated from
+    diffusion.py:183-189.  One file per case: tests/golden/full_<case>.npz with the stride-4 sub-sample of x_0 and of
+    the last x0|t, per-image PSNR vs x_orig, full-tensor statistics and three intermediate x0|t (captured as the
+    argument of the loop's `torch.randn_like(x0_t)`).  CPU cost on 8 threads: c2b8 ~17 min, c3 ~8 min, c4 ~25 min,
+    c5 ~13 min."""
+    import time
+    import torch.nn.functional as F
+    from oracle import sampler, weights
+    ns = ref_import.load()
+    R = ns.svd_operators
+    torch.set_num_threads(os.cpu_count())
+    mask_real = torch.from_numpy(np.load(os.path.join(ref_import.REF_ROOT, "exp/inp_masks/mask.npy")))
+    for name in names:
+        c, cfg, sd, x_orig, x_T, tape = cases.full_case(name)
+        if c["net"] == "celeba":
+            ref = ns.models.Model(cfg)
+        else:
+            ref = ns.script_util.create_model(**vars(cfg.model))
+        ref.load_state_dict(sd)
+        ref.eval()
+        cls_fn = None
+        if c["class_cond"]:
+            cc = weights.classifier_config()
+            clf = ns.script_util.create_classifier(**{k: getattr(cc, k) for k in ns.script_util.classifier_defaults()})
+            clf.load_state_dict(weights.classifier_state_dict(cc))
+            clf.eval()
+
+            def cls_fn(x, t, y, clf=clf, scale=cc.classifier_scale):          # diffusion.py:183-189
+                with torch.enable_grad():
+                    x_in = x.detach().requires_grad_(True)
+                    logits = clf(x_in, t)
+                    log_probs = F.log_softmax(logits, dim=-1)
+                    selected = log_probs[range(len(logits)), y.view(-1)]
+                    return torch.autograd.grad(selected.sum(), x_in)[0] * scale
+        op = ref_operator(R, c["deg"], 256, mask_real if c["deg"] == "inpainting" else None)
+        y = op.A(x_orig)
+        times = schedule.jump_times(c["T"], *c["travel"])
+        for k in c["record"]:
+            assert times[k + 1] < times[k], f"record index {k} of {name} is not a reverse step"
+        inter = {}
+
+        def on_call(k, x0_t, inter=inter, want=c["record"]):
+            if k in want:
+                inter[k] = x0_t.detach().clone()
+        t0 = time.perf_counter()
+        with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape, on_call=on_call):
+            xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, cls_fn=cls_fn,
+                                                 classes=None, config=cfg)
+        dt = time.perf_counter() - t0
+        x, x0 = xs[0], x0s[0]
+        out = dict(x_sub=sub(x, 4), x0_sub=sub(x0, 4), psnr=sampler.psnr(x, x_orig).numpy(),
+                   stats=np.array([x.double().mean().item(), x.double().std().item(), x.double().abs().sum().item()]),
+                   consistency=np.array([(op.A(x) - y).abs().max().item()]),
+                   record_k=np.array(c["record"]), ref_cpu_seconds=np.array([dt]),
+                   ref_cpu_threads=np.array([torch.get_num_threads()]))
+        for k, v in inter.items():
+            out[f"x0_k{k}_sub"] = sub(v, 4)
+            out[f"x0_k{k}_stats"] = np.array([v.double().mean().item(), v.double().std().item(),
+                                              v.double().abs().sum().item()])
+        np.savez_compressed(os.path.join(HERE, f"full_{name}.npz"), **out)
+        print(f"full {name}: {dt:.1f} s on {torch.get_num_threads()} threads, psnr {out['psnr']}, "
+              f"consistency {out['consistency']}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--full-cases", default="", help="comma list of c2b8,c3,c4,c5: run the FULL BASELINE "
+                    "configurations through the reference (tests/golden/full_<case>.npz; up to 25 min of CPU each)")
     ap.add_argument("--adm-only", action="store_true", help="only (re)generate the ADM UNet goldens")
     ap.add_argument("--plus-only", action="store_true", help="only (re)generate the DDNM+ goldens")
     ap.add_argument("--plus-deblur-only", action="store_true", help="only (re)generate the DDNM+ deblurring goldens")
@@ -346,6 +415,8 @@ def main():
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     args = ap.parse_args()
+    if args.full_cases:
+        return make_full(args.full_cases.split(","))
     if args.classifier_only:
         return make_classifier()
     if args.plus_deblur_only:

@@ -12,20 +12,27 @@ sys.path.insert(0, ROOT)
 from ddnm_amd._lib import ConvDesc  # noqa: E402
 
 CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
-OUT = os.path.join(ROOT, "gpurun_out")
+OUT = os.path.join(ROOT, "tools", "_build")      # git-ignored, but travels with gpurun (prebuilt here)
 VARIANTS = {"base": [], "no_res_fold": ["-DDDNM_PROBE_NO_RES_FOLD"]}
-if len(sys.argv) > 1:
-    VARIANTS = {"base": [], **{f"v{i}": a.split() for i, a in enumerate(sys.argv[1:])}}
+BUILD_ONLY = "--build-only" in sys.argv
+_args = [a for a in sys.argv[1:] if a != "--build-only"]
+if _args:
+    VARIANTS = {"base": [], **{f"v{i}": a.split() for i, a in enumerate(_args)}}
 os.makedirs(OUT, exist_ok=True)
 libs = {}
 for n, fl in VARIANTS.items():
     so = os.path.join(OUT, f"libprobe16_{n}.so")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + fl +
-                   [os.path.join(CSRC, "conv_igemm_f16.hip"), "-o", so], check=True)
+    if not os.path.exists(so) or BUILD_ONLY:
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + fl +
+                       [os.path.join(CSRC, "conv_igemm_f16.hip"), "-o", so], check=True)
+    if BUILD_ONLY:
+        continue
     lib = ctypes.CDLL(so)
     lib.ddnm_conv3x3_f16_f32.restype = ctypes.c_int32
     lib.ddnm_conv3x3_f16_f32.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_void_p]
     libs[n] = lib
+if BUILD_ONLY:
+    sys.exit(0)
 dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
 wsb = torch.empty(64 << 20, device=dev)

@@ -1,47 +1,70 @@
 #!/usr/bin/env python
-"""Development probe: fp16-operand 3x3 convolution on ADM layer shapes (B=4)."""
+"""Development probe: ablation builds of conv16.hip (WRONG results on purpose) over a K sweep, to separate the
+per-launch fixed cost (dispatch, prologue, epilogue) from the main-loop rate."""
+import ctypes
 import os
+import subprocess
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ddnm_amd import ops  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ddnm_amd._lib import Conv16Desc  # noqa: E402
 
-SHAPES = [  # name, B, C0, C1, Cout, H, gn, res
-    ("warm", 4, 256, 0, 256, 256, 1, 1),
-    ("256_256_256_gn_res", 4, 256, 0, 256, 256, 1, 1),
-    ("256_256_256_plain", 4, 256, 0, 256, 256, 0, 0),
-    ("512cat_256_256_gn", 4, 256, 256, 256, 256, 1, 0),
-    ("256_256_128_gn_res", 4, 256, 0, 256, 128, 1, 1),
-    ("512_512_128_gn_res", 4, 512, 0, 512, 128, 1, 1),
-    ("512_512_64_gn_res", 4, 512, 0, 512, 64, 1, 1),
-    ("1024_512_64_gn", 4, 512, 512, 512, 64, 1, 0),
-    ("512_512_32_gn_res", 4, 512, 0, 512, 32, 1, 1),
-    ("1024_1024_32_gn_res", 4, 1024, 0, 1024, 32, 1, 1),
-    ("1024_1024_16_gn_res", 4, 1024, 0, 1024, 16, 1, 1),
-]
+CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "_build")
+VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16_NO_MAIN"]}
+extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+for i, a in enumerate(extra):
+    VARIANTS[f"x{i}"] = a.split(",")
+BUILD_ONLY = "--build-only" in sys.argv
+os.makedirs(OUT, exist_ok=True)
+libs = {}
+for n, fl in VARIANTS.items():
+    so = os.path.join(OUT, f"libp16_{n}.so")
+    if not os.path.exists(so) or BUILD_ONLY:
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + fl +
+                       [os.path.join(CSRC, "conv16.hip"), "-o", so], check=True)
+    if BUILD_ONLY:
+        continue
+    lib = ctypes.CDLL(so)
+    lib.ddnm_conv16.restype = ctypes.c_int32
+    lib.ddnm_conv16.argtypes = [ctypes.POINTER(Conv16Desc), ctypes.c_void_p]
+    libs[n] = lib
+if BUILD_ONLY:
+    sys.exit(0)
 dev = "cuda"
-for name, B, C0, C1, Cout, H, gn, res in SHAPES:
-    a = torch.randn(B, H, H, C0, device=dev)
-    b = torch.randn(B, H, H, C1, device=dev) if C1 else None
-    w = torch.randn(Cout, C0 + C1, 3, 3, device=dev) * 0.02
-    w32, w16 = ops.pack_conv_weight(w), ops.pack_conv_weight_f16(w)
+stream = torch.cuda.current_stream().cuda_stream
+B = 4
+print("shape                 " + " ".join(f"{n:>10s}" for n in libs) + "   (us)")
+for name, Cin, Cout, H, k, res in [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
+                                   ("256->256@256 res", 256, 256, 256, 3, 1), ("256->256@256", 256, 256, 256, 3, 0),
+                                   ("512->256@256", 512, 256, 256, 3, 0), ("1024->256@256", 1024, 256, 256, 3, 0),
+                                   ("256->256@128 res", 256, 256, 128, 3, 1), ("512->512@128 res", 512, 512, 128, 3, 1),
+                                   ("512->512@64 res", 512, 512, 64, 3, 1), ("256->256@256 1x1", 256, 256, 256, 1, 0),
+                                   ("1024->256@256 1x1", 1024, 256, 256, 1, 0)]:
+    x = torch.randn(B, H, H, Cin, device=dev).half()
+    w = (torch.randn(Cout, k * k, Cin, device=dev) * 0.02).half()
     bias = torch.randn(Cout, device=dev)
-    g = (torch.randn(B, C0 + C1, device=dev), torch.randn(B, C0 + C1, device=dev)) if gn else None
-    r = torch.randn(B, H, H, Cout, device=dev) if res else None
-    out = torch.empty(B, H, H, Cout, device=dev)
-    flops = 2.0 * B * H * H * Cout * 9 * (C0 + C1)
+    r = torch.randn(B, H, H, Cout, device=dev).half()
+    out = torch.empty(B, H, H, Cout, device=dev, dtype=torch.float16)
+    stats = torch.empty(B * (H * H // 128) * Cout * 2, device=dev)
+    d = Conv16Desc()
+    d.src, d.weight, d.bias, d.out, d.stats_out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), stats.data_ptr()
+    d.res = r.data_ptr() if res else None
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, H, Cin, Cout, k
     row = []
-    for wf in (w16, None):
+    for n, lib in libs.items():
         for _ in range(2):
-            ops.conv2d(a, w32, Cout, 3, src1=b, bias=bias, gn=g, res=r, out=out, weight_f16=wf)
+            assert lib.ddnm_conv16(ctypes.byref(d), stream) == 0
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            ops.conv2d(a, w32, Cout, 3, src1=b, bias=bias, gn=g, res=r, out=out, weight_f16=wf)
+            lib.ddnm_conv16(ctypes.byref(d), stream)
         e1.record()
         torch.cuda.synchronize()
-        row.append(flops / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e12)
-    print(f"{name:24s} f16 {row[0]:7.1f}   f32 {row[1]:6.1f}  TFLOP/s", flush=True)
+        row.append(e0.elapsed_time(e1) / 10 * 1e3)
+    fl = 2.0 * B * H * H * Cout * k * k * Cin
+    print(f"{name:22s} " + " ".join(f"{v:10.1f}" for v in row) + f"   base {fl / row[0] / 1e6:7.1f} TF/s", flush=True)

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from ddnm_amd._lib import ConvDesc  # noqa: E402
 
 CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
-OUT = os.path.join(ROOT, "gpurun_out")
+OUT = os.path.join(ROOT, "tools", "_build")      # git-ignored, but travels with gpurun (prebuilt here)
 
 VARIANTS = {
     "base": [],
@@ -49,7 +49,10 @@ def build(name, flags):
     so = os.path.join(OUT, f"libprobe_{name}.so")
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + flags + \
           [os.path.join(CSRC, "conv_igemm_f32.hip"), "-o", so]
-    subprocess.run(cmd, check=True)
+    if not os.path.exists(so) or "--rebuild" in sys.argv:
+        subprocess.run(cmd, check=True)
+    if "--build-only" in sys.argv:
+        return None
     lib = ctypes.CDLL(so)
     lib.ddnm_conv2d_f32.restype = ctypes.c_int32
     lib.ddnm_conv2d_f32.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_void_p]
@@ -58,8 +61,10 @@ def build(name, flags):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1:] or list(VARIANTS)
+    only = [a for a in sys.argv[1:] if not a.startswith("--")] or list(VARIANTS)
     libs = {n: build(n, VARIANTS[n]) for n in only}
+    if "--build-only" in sys.argv:
+        return
     dev = "cuda"
     ws = torch.empty(64 << 20, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
