@@ -13,6 +13,11 @@ Synthetic inputs, seeded random weights of the real architecture (no checkpoints
 N>1: one process per GPU, every rank restores its own batch of 8 (weak scaling), one RCCL
 all_gather of the restored images at the end of each step (inside the timed region).
 Prints ONE JSON line on rank 0.
+
+At 1 GPU the default run appends `"workloads": {"c3", "c4", "c5"}`: the per-GPU shards of BASELINE configs[2..4]
+(ImageNet ADM UNet in the runner's fp16 mode), 1 warm-up + 2 timed restorations each, each with its own
+`roofline` against the 2.5 PFLOP/s fp16 MFMA peak (`--no-extra-workloads` skips them; `--workload c3 --scaling
+strong` times configs[2] / configs[3] with their fixed GLOBAL batch of 32 / 16 split over the ranks).
 """
 import argparse
 import json
@@ -56,9 +61,9 @@ def make_config():
 def cpu_baseline(cfg, sd, budget_s=25.0):
     """Reported baseline (not the optimisation target): the oracle restatement of the reference path
     (bit-identical to the reference UNet on CPU, tests/test_oracle_pins.py) on this box's host cores.
-    Bounded sample: B=1, as many reverse steps of the 100 as fit in `budget_s`, extrapolated.
-    The intra-op thread count is calibrated first on a reduced UNet (oversubscribing a many-core
-    host makes the ATen CPU kernels dramatically slower)."""
+    Bounded sample: B=1, as many reverse steps of the 100 as fit in `budget_s`, extrapolated; then the workload's own
+    batch (B=8) for 3 reverse steps, reported next to it (`b8_value`).  The intra-op thread count is calibrated
+    first on a reduced UNet (oversubscribing a many-core host makes the ATen CPU kernels dramatically slower)."""
     from oracle import cases, sampler, unet_celeba
     try:
         avail = len(os.sched_getaffinity(0))
@@ -81,55 +86,85 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
             best = (nt, dt)
     threads = best[0] or min(avail, 8)
     torch.set_num_threads(threads)
-
-    x_orig, x_T, tape = cases.sampler_case(cfg, 1, T_SAMPLING)
-    op = cases.make_operator("sr_bicubic", 256)
-    y = op.A(x_orig)
     net = unet_celeba.Net(sd, cfg)
-    t0 = time.perf_counter()
-    net(x_T, torch.tensor([990.0]))          # warm-up forward, also sizes the sample
-    t_fwd = time.perf_counter() - t0
-    n_steps = int(max(1, min(10, budget_s // max(t_fwd, 1e-3))))
+    op = cases.make_operator("sr_bicubic", 256)
 
     class Stop(Exception):
         pass
 
-    def record(k, name, t):
-        if name == "xt_next" and k == n_steps - 1:
-            raise Stop
+    def timed(batch, n_steps):
+        x_orig, x_T, tape = cases.sampler_case(cfg, batch, n_steps)
+        y = op.A(x_orig)
+
+        def record(k, name, t):
+            if name == "xt_next" and k == n_steps - 1:
+                raise Stop
+        t0 = time.perf_counter()
+        try:
+            sampler.ddnm_diffusion(x_T, net, cases.betas(), 0.85, op, y, tape, record=record)
+        except Stop:
+            pass
+        return time.perf_counter() - t0
 
     t0 = time.perf_counter()
+    net(torch.zeros(1, 3, 256, 256), torch.tensor([990.0]))          # warm-up forward, also sizes the sample
+    t_fwd = time.perf_counter() - t0
+    n_steps = int(max(1, min(10, (budget_s * 0.6) // max(t_fwd, 1e-3))))
+    dt = timed(1, n_steps)
+    out = {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"B=1, {n_steps} of {T_SAMPLING} reverse steps timed ({dt:.1f} s) on {threads} threads ({avail} "
+                     f"logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}; `b8_value`: the workload's own batch "
+                     "of 8 for 3 reverse steps, same extrapolation"}
     try:
-        sampler.ddnm_diffusion(x_T, net, cases.betas(), 0.85, op, y, tape, record=record)
-    except Stop:
-        pass
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": threads,
-            "kind": "port", "sample": f"B=1, {n_steps} of {T_SAMPLING} reverse steps timed ({dt:.1f} s) on {threads} "
-                                      f"threads ({avail} logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}"}
+        dt8 = timed(BATCH_PER_GPU, 3)
+        out["b8_value"] = BATCH_PER_GPU / (dt8 / 3 * T_SAMPLING)
+        out["b8_seconds_for_3_steps"] = round(dt8, 2)
+    except Exception as e:    # noqa: BLE001
+        out["b8_value"] = None
+        out["b8_error"] = repr(e)
+    return out
 
 
-def bench_adm(args, ddist, rank, world, dev):
-    """Informational ImageNet workloads (BASELINE configs[2], configs[3] per-GPU shards): ADM UNet
-    (552.81 M params, 2242.87 GFLOP per forward per image), fp16-operand MFMA torso."""
+# ------------------------------------------------------------------------------------------------- ImageNet workloads
+ADM_FLOPS_PER_FWD = 2242.87e9          # SURVEY.md section 8(d), per image
+ADM_CC_FLOPS_PER_STEP = 2243.9e9 + 300e9      # class-conditional UNet + classifier forward / input-gradient (estimate)
+PEAK_F16_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
+ADM_WORKLOADS = {
+    "c3": dict(desc="imagenet_256.yml colorization, T_sampling=100 (BASELINE configs[2]: batch_size=32 sharded across "
+                    "8 GPUs = 4 images per GPU)", batch=4, travel=(1, 1), global_batch=32, ranks=8),
+    "c4": dict(desc="imagenet_256.yml inpainting, time travel l=10 r=3: 280 NFE + 180 re-noise steps (BASELINE configs[3]: "
+                    "batch_size=16 on 4 GPUs = 4 images per GPU)", batch=4, travel=(10, 3), global_batch=16, ranks=4),
+    "c5": dict(desc="imagenet_256_cc.yml cs_walshhadamard 0.25, class-conditional ADM + classifier guidance (class 951, "
+                    "scale 1.0), batch_size=8 on 1 GPU (BASELINE configs[4])", batch=8, travel=(1, 1), global_batch=8,
+               ranks=1),
+}
+
+
+def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roofline=True):
+    """One ImageNet workload: ADM UNet (552.81 M parameters, 2242.87 GFLOP per forward per image) in the runner's
+    `use_fp16: true` mode = fp16 activations + fp16 MFMA operands, fp32 accumulation (ddnm_amd/guided_diffusion/unet.py).
+    weak scaling (default): every rank restores the per-GPU shard of the BASELINE config; `strong`: the config's GLOBAL
+    batch is split over the ranks present.  Returns the result dict (rank 0 prints it)."""
     import types
+    from ddnm_amd import ops
     from ddnm_amd.functions.svd_ddnm import ddnm_diffusion, get_schedule_jump
     from ddnm_amd.functions.svd_operators import Colorization, Inpainting, WalshHadamardCS
     from ddnm_amd.guided_diffusion.classifier import classifier_defaults, create_classifier, make_cond_fn
     from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
     from ddnm_amd.guided_diffusion.unet import create_model
+    W = ADM_WORKLOADS[name]
     ns = types.SimpleNamespace
-    travel = (10, 3) if args.workload == "c4" else (1, 1)
+    travel = W["travel"]
     cfg = ns(diffusion=ns(num_diffusion_timesteps=1000), data=ns(image_size=256, channels=3),
              time_travel=ns(T_sampling=T_SAMPLING, travel_length=travel[0], travel_repeat=travel[1]))
     model = create_model(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8",
                          num_head_channels=64, learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True,
-                         use_fp16=True, class_cond=(args.workload == "c5"))
+                         use_fp16=True, class_cond=(name == "c5"))
     model.device = dev
     model.load_state_dict(model.random_state_dict(1234))
     model.convert_to_fp16()
     cls_fn = None
-    if args.workload == "c5":
+    if name == "c5":
         kw = classifier_defaults()
         kw["image_size"] = 256
         clf = create_classifier(**kw)
@@ -143,12 +178,16 @@ def bench_adm(args, ddist, rank, world, dev):
         cls_fn = make_cond_fn(clf, 1.0)
     betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
                                                num_diffusion_timesteps=1000)).float().to(dev)
-    B = 8 if args.workload == "c5" else 4
+    if strong:
+        lo, hi = ddist.shard_range(W["global_batch"], rank, world)
+        B, n_total = hi - lo, W["global_batch"]
+    else:
+        B, n_total = W["batch"], W["batch"] * world
     g = torch.Generator().manual_seed(1234 + rank)
-    x_orig = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
-    if args.workload == "c3":
+    x_orig = (torch.rand(max(B, 1), 3, 256, 256, generator=g) * 2 - 1).to(dev)
+    if name == "c3":
         op = Colorization(256, dev)
-    elif args.workload == "c5":
+    elif name == "c5":
         op = WalshHadamardCS(3, 256, 4, torch.randperm(256 * 256, generator=g), dev)
     else:
         mask = (torch.rand(256, 256, generator=g) > 0.26).long().reshape(-1)        # 74 % kept, like exp/inp_masks/mask.npy
@@ -159,16 +198,16 @@ def bench_adm(args, ddist, rank, world, dev):
     nfe = sum(1 for a, b in zip(times[:-1], times[1:]) if b < a)
 
     def one_pass():
-        x_T = torch.randn(B, 3, 256, 256, device=dev)
-        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=cls_fn, classes=None, config=cfg)
-        return ddist.gather_images(xs[0])
+        x_T = torch.randn(max(B, 1), 3, 256, 256, device=dev)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=cls_fn, classes=None, config=cfg, return_cpu=False)
+        return ddist.gather_images(xs[0][:B], n_total=n_total)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         out = one_pass()
     ddist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = one_pass()
     torch.cuda.synchronize()
     ddist.barrier()
@@ -177,25 +216,59 @@ def bench_adm(args, ddist, rank, world, dev):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = tmax.item()
-    value = args.steps * B * world / dt
-    tfl = value * nfe * (2243.9e9 + 300e9 if args.workload == "c5" else 2242.87e9) / 1e12 / world
-    line = {"metric": "restored images/sec @256x256, 100 DDIM steps", "value": round(value, 4), "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 operands / f32 accumulate",
-            "data": "synthetic",
-            "config": {"workload": {"c3": "imagenet_256.yml colorization, T_sampling=100, batch 4 per GPU (BASELINE configs[2] shard)",
-                                    "c4": "imagenet_256.yml inpainting, time-travel l=10 r=3 (280 NFE + 180 re-noise), "
-                                          "batch 4 per GPU (BASELINE configs[3] shard)",
-                                    "c5": "imagenet_256_cc.yml cs_walshhadamard ratio 0.25, class-conditional ADM + classifier "
-                                          "guidance (class 951, scale 1.0; classifier fwd + input-gradient on fp16 MFMA operands), batch 8 "
-                                          "on 1 GPU (BASELINE configs[4])"}[args.workload],
-                       "global_batch": B * world, "nfe_per_image": nfe},
-            "whole_loop_tflops_per_gpu": round(tfl, 1), "finite": bool(torch.isfinite(out).all())}
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        ddist.barrier()
-        torch.distributed.destroy_process_group()
+    value = steps * n_total / dt
+    per_step = ADM_CC_FLOPS_PER_STEP if name == "c5" else ADM_FLOPS_PER_FWD
+    tfl = value * nfe * per_step / 1e12 / world
+    res = {"value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 2), "scaling": "strong" if strong else "weak",
+           "dtype": "f16 (activations and MFMA operands; f32 accumulate, GroupNorm statistics, softmax)",
+           "data": "synthetic",
+           "config": {"workload": W["desc"], "global_batch": n_total, "per_gpu_batch": B, "nfe_per_image": nfe},
+           "whole_loop_tflops_per_gpu": round(tfl, 1), "whole_loop_frac": round(tfl / PEAK_F16_TFLOPS, 4),
+           "finite": bool(torch.isfinite(out).all())}
+    if roofline and rank == 0 and B > 0:
+        try:
+            timer = ops.KernelTimer()
+            ops.set_kernel_timer(timer)
+            x_T = torch.randn(B, 3, 256, 256, device=dev)
+            t = torch.full((B,), 500.0, device=dev)
+            cls = torch.full((B,), 951, dtype=torch.long, device=dev)
+            for _ in range(2):
+                model(x_T, t, cls) if name == "c5" else model(x_T, t)
+            ops.set_kernel_timer(None)
+            summ = timer.summary()
+            kname, r = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            total_ms = sum(v["ms"] for v in summ.values())
+            achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                               "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                               "avg_flops_per_launch": r["flops"] / r["launches"],
+                               "share_of_conv_time": round(r["ms"] / total_ms, 4),
+                               "note": "HIP events around every launch of the kernel during 2 UNet forwards at this batch"}
+        except Exception as e:    # noqa: BLE001
+            ops.set_kernel_timer(None)
+            res["roofline"] = {"error": repr(e)}
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
+def pmc_for_loaded_binary(lib_digest):
+    """HBM traffic / MFMA-busy of the dominant kernel come from separate rocprofv3 --pmc passes (bench.py cannot run
+    under the profiler itself); tools/pmc_summary.py stamps them with the digest of the sources the profiled binary was
+    built from.  They are reported ONLY when that digest is the loaded library's -- a kernel edit invalidates them."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc_dominant_kernel.json"):
+            try:
+                pj = json.load(open(os.path.join(pdir, f)))
+            except Exception:      # noqa: BLE001
+                continue
+            if pj.get("source_digest") == lib_digest:
+                best = (f, pj)
+    return best
 
 
 def main():
@@ -204,14 +277,18 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
-                    help="c2 (default, headline): celeba_hq sr_bicubic 4x B=8/GPU, fp32.  Informational extras: "
-                         "c3 = imagenet_256 colorization B=4/GPU, c4 = imagenet_256 inpainting with time travel "
-                         "l=10 r=3 B=4/GPU, c5 = imagenet_256_cc cs_walshhadamard 0.25 + classifier guidance "
-                         "B=8 (ADM UNet, fp16-operand torso like the reference's use_fp16)")
+                    help="c2 (default, headline): celeba_hq sr_bicubic 4x B=8/GPU, fp32.  c3 = imagenet_256 colorization, "
+                         "c4 = imagenet_256 inpainting with time travel l=10 r=3, c5 = imagenet_256_cc cs_walshhadamard "
+                         "0.25 + classifier guidance (ADM UNet in the runner's use_fp16 mode)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="c3 / c4 only: strong = the BASELINE config's global batch (32 / 16) split over the ranks")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="default c2 run at 1 GPU: do not append the short c3 / c4 / c5 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    from ddnm_amd import _lib
     from ddnm_amd import dist as ddist
     from ddnm_amd import ops
     from ddnm_amd.functions.svd_ddnm import ddnm_diffusion
@@ -224,10 +301,21 @@ def main():
         if rank == 0:
             sys.stderr.write(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE\n")
     dev = torch.device("cuda", torch.cuda.current_device())
+    lib_digest = _lib.lib().ddnm_build_digest().decode()
 
     cfg = make_config()
     if args.workload != "c2":
-        return bench_adm(args, ddist, rank, world, dev)
+        res = adm_workload(args.workload, ddist, rank, world, dev, args.steps, args.warmup,
+                           strong=(args.scaling == "strong"), roofline=not args.no_roofline)
+        line = {"metric": "restored images/sec @256x256, 100 DDIM steps", "higher_is_better": True, "vs_baseline": None,
+                "library_digest": lib_digest[:16]}
+        line.update(res)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            ddist.barrier()
+            torch.distributed.destroy_process_group()
+        return
     model = Model(cfg, device=dev)
     sd = model.random_state_dict(seed=1234)          # identical replica on every rank, no broadcast
     model.load_state_dict(sd)
@@ -242,7 +330,7 @@ def main():
 
     def one_pass():
         x_T = torch.randn(B, 3, 256, 256, device=dev)
-        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg, return_cpu=False)
         return ddist.gather_images(xs[0])            # the path's single collective
 
     for _ in range(args.warmup):
@@ -273,7 +361,7 @@ def main():
         "config": {"workload": "celeba_hq.yml SVD sr_bicubic 4x, sigma_y=0, eta=0.85, T_sampling=100, "
                                "batch_size=8 per GPU (BASELINE configs[1])",
                    "global_batch": B * world, "image": "3x256x256", "parallelism": f"dp{world} (image sharding)"},
-        "consistency_max_abs": resid,
+        "consistency_max_abs": resid, "library_digest": lib_digest[:16],
     }
 
     if rank == 0 and not args.no_roofline:
@@ -300,17 +388,22 @@ def main():
                                       + b_ * ho * wo * cout * (2 if has_res else 1)))
             total_ms = sum(v["ms"] for v in summ.values())
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
-            # HBM traffic / MFMA-busy of the same kernel come from separate rocprofv3 --pmc passes (bench.py cannot
-            # run under the profiler itself); tools/pmc_summary.py writes them to profiles/.
-            traffic, mfma_busy = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
-            if os.path.exists(pmc):
-                pj = json.load(open(pmc))
+            traffic, mfma_busy, frac_rocprof, pmc_note = None, None, None, \
+                "no profiles/*_pmc_dominant_kernel.json carries the loaded library's source digest: traffic / MFMA-busy " \
+                "are not reported for this binary"
+            hit = pmc_for_loaded_binary(lib_digest)
+            if hit is not None:
+                fname, pj = hit
                 traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_busy_frac_weighted")
+                if pj.get("rocprof_avg_launch_us"):
+                    frac_rocprof = round(r["flops"] / r["launches"] / (pj["rocprof_avg_launch_us"] * 1e-6) / 1e12
+                                         / PEAK_F32_TFLOPS, 4)
+                pmc_note = f"HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, MFMA-busy and the rocprofv3 average " \
+                           f"launch time from profiles/{fname} (same source digest as the loaded library)"
             line["roofline"] = {
                 "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_dominant_kernel.json",
+                "frac_rocprof": frac_rocprof, "traffic_note": pmc_note,
                 "traffic_algorithmic": round(sum(alg) / max(1, len(alg)), 1),
                 "mfma_busy_pmc": mfma_busy,
                 "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
@@ -324,6 +417,16 @@ def main():
             line["roofline"] = {"error": repr(e)}
     if world > 1:
         ddist.barrier()
+    if world == 1 and not args.no_extra_workloads:
+        # BASELINE configs[2..4] on this GPU (their per-GPU shards), short: 1 warm-up + 2 timed restorations each
+        del model
+        torch.cuda.empty_cache()
+        line["workloads"] = {}
+        for wname in ("c3", "c4", "c5"):
+            try:
+                line["workloads"][wname] = adm_workload(wname, ddist, rank, world, dev, 2, 1, roofline=not args.no_roofline)
+            except Exception as e:    # noqa: BLE001
+                line["workloads"][wname] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -55,6 +55,8 @@ class Conv16Desc(Structure):
         ("Cin", c_int32), ("Cout", c_int32), ("ksize", c_int32),
         ("ups", c_int32), ("res_ups", c_int32),
         ("SC0", c_int32), ("SC1", c_int32),
+        ("src1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p),
+        ("C0", c_int32), ("gn_silu", c_int32),
         ("out_nchw_f32", c_int32), ("reserved", c_int32),
     ]
 
@@ -68,6 +70,8 @@ class StepScalars(Structure):
 PROTOTYPES = {
     "ddnm_version": (c_int32, []),
     "ddnm_error_string": (c_char_p, [c_int32]),
+    "ddnm_build_digest": (c_char_p, []),
+    "ddnm_sizeof": (c_int32, [c_int32]),
     "ddnm_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
@@ -133,7 +137,7 @@ PROTOTYPES = {
     "ddnm_timestep_embedding_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_avgpool2_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                          c_int32, c_void_p]),
-    "ddnm_embedding_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ddnm_embedding_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_nchw_to_nhwc_pad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_step_x0_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, POINTER(StepScalars),
                                    c_void_p]),
@@ -178,10 +182,26 @@ class DDNMHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2
+
+
 def lib():
-    """The loaded shared library; raises if it has not been built (no fallback)."""
+    """The loaded shared library; raises if it has not been built (no fallback).
+
+    The binary is git-ignored and shipped prebuilt, so it identifies itself: `ddnm_build_digest()` must equal the
+    sha256 of the sources lying next to it (ddnm_amd/build.py::_digest).  A missing or stale binary is rebuilt when
+    hipcc is available (DDNM_NO_AUTOBUILD=1 disables that) and otherwise refused; the descriptor structs' sizes are
+    checked against the ctypes mirrors as well."""
     global _lib
     if _lib is None:
+        from . import build as _build
+        want = _build._digest()
+        stale = not os.path.exists(LIB_PATH) or not os.path.exists(_build.STAMP) or open(_build.STAMP).read() != want
+        if stale and os.environ.get("DDNM_NO_AUTOBUILD") != "1":
+            try:
+                _build.build(force=False)
+            except Exception as e:      # noqa: BLE001
+                raise DDNMHipError(f"{LIB_PATH} is missing or older than its sources and could not be rebuilt: {e}")
         if not os.path.exists(LIB_PATH):
             raise DDNMHipError(
                 f"{LIB_PATH} is missing: build it with `python -m ddnm_amd.build` "
@@ -195,6 +215,16 @@ def lib():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        got = l.ddnm_build_digest().decode()
+        if got != want:
+            raise DDNMHipError(f"{LIB_PATH} was built from different sources (binary {got[:12]}, sources {want[:12]}): "
+                               "rebuild it with `python -m ddnm_amd.build --force`")
+        if l.ddnm_version() != ABI_VERSION:
+            raise DDNMHipError(f"ABI version {l.ddnm_version()} != {ABI_VERSION}")
+        for idx, st in enumerate((ConvDesc, GemmDesc, Conv16Desc, StepScalars)):
+            if l.ddnm_sizeof(idx) != ctypes.sizeof(st):
+                raise DDNMHipError(f"{st.__name__}: ctypes mirror is {ctypes.sizeof(st)} bytes, the binary's struct "
+                                   f"{l.ddnm_sizeof(idx)}")
         _lib = l
     return _lib
 

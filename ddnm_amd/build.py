@@ -29,11 +29,19 @@ def _digest():
     return h.hexdigest()
 
 
+LAST_BUILD = {"compiled": False}      # whether the last build() call ran hipcc (reported by __graft_entry__.build)
+
+
 def build(force=False, verbose=False):
+    """Compile libddnm_hip.so unless the stamp says it already matches the sources.  The digest is also compiled
+    INTO the binary (ddnm_build_digest()), which is what the loader trusts."""
     dig = _digest()
+    LAST_BUILD["compiled"] = False
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    LAST_BUILD["compiled"] = True
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [_hipcc()] + FLAGS + [f'-DDDNM_BUILD_DIGEST="{dig}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -42,6 +50,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed")
     if verbose and r.stderr:
         sys.stderr.write(r.stderr)
+    os.replace(tmp, LIB)               # atomic: a concurrent loader never maps a half-written file
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     // weight rows: 32 pieces of 8 rows, wave w takes pieces w, w+8, w+16, w+24
     const unsigned wrow0 = (unsigned)(n_tile * BN + wave * 8 + lrow);
     const unsigned src_pix = (unsigned)d.B * p.Hs * p.Ws, out_pix = (unsigned)p.M;
-    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(d.src, src_pix * Cin * 2u);
+    const int C0 = d.src1 ? d.C0 : Cin, C1 = Cin - C0;           // operand = channel concat of two NHWC tensors
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(d.src, src_pix * C0 * 2u);
+    const __amdgpu_buffer_rsrc_t r_src1 = make_rsrc(d.src1 ? d.src1 : d.src, src_pix * C1 * 2u);
     const __amdgpu_buffer_rsrc_t r_w = make_rsrc(d.weight, (unsigned)p.n_tiles * BN * TAPS * Cin * 2u);
 
     // halo rows of channels [coff, coff+64) of the NHWC tensor behind `rsrc` (`cstride` channels per pixel)
@@ -141,11 +143,45 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     auto issue_w = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned rowlen, unsigned delta, int wb) {
         char* dst = Wb + wb * G::WBYTES + wave * 1024;
         const unsigned vo = (wrow0 * rowlen + lp8) * 2u;
+#ifdef DDNM_P16_NO_WLOAD
+        if (rowlen != 12345u) return;
+#endif
         if (WNW == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bload16(rsrc, vo, (delta + 64u * j * rowlen) * 2u, dst + j * 8192);
         } else if (wave < BN / 8) {
             bload16(rsrc, vo, delta * 2u, dst);
+        }
+    };
+
+    // halo of main-operand chunk `c` (64 channels of the concat)
+    auto issue_main_halo = [&](int c, int hb) {
+        const int cb = c * C16_KC;
+        if (cb < C0) issue_halo(r_src, C0, cb, hb);
+        else issue_halo(r_src1, C1, cb - C0, hb);
+    };
+    // ---- fused GroupNorm (+FiLM) affine + swish of the operand, applied IN LDS: each lane transforms exactly the
+    // 16-byte pieces it fetched (so it needs no barrier, only its own vmcnt wait, knows which rows are zero padding --
+    // the reference pads the ACTIVATED tensor -- and which 8 channels it holds: lp8 .. lp8+7 of the chunk).
+    const bool fuse_gn = TAPS == 9 && d.gn_scale != nullptr;
+    f32x4 gsc0, gsc1, gsh0, gsh1;
+    auto load_gn = [&](int c) {
+        const float* sc = d.gn_scale + (size_t)img * Cin + c * C16_KC + lp8;
+        const float* sh = d.gn_shift + (size_t)img * Cin + c * C16_KC + lp8;
+        gsc0 = *reinterpret_cast<const f32x4*>(sc); gsc1 = *reinterpret_cast<const f32x4*>(sc + 4);
+        gsh0 = *reinterpret_cast<const f32x4*>(sh); gsh1 = *reinterpret_cast<const f32x4*>(sh + 4);
+    };
+    auto act_group = [&](int gi, int hb) {
+        if (wave + 8 * gi < G::HGROUPS && hoff[gi] >= 0) {
+            char* pl = Hb + hb * G::HBYTES + (wave + 8 * gi) * 1024 + lane * 16;
+            const half8 v = *reinterpret_cast<const half8*>(pl);
+            f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            f32x4 b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+            a = gn_act(a, gsc0, gsh0, d.gn_silu);
+            b = gn_act(b, gsc1, gsh1, d.gn_silu);
+            const half8 o = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                             (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+            *reinterpret_cast<half8*>(pl) = o;
         }
     };
 
@@ -189,8 +225,13 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+#ifdef DDNM_P16_NO_FRAG
+            const int cur = 0, nxt = 0;
+            if (false) {
+#else
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 4) {
+#endif
 #pragma unroll
                 for (int j = 0; j < NT; ++j) a[nxt][j] = *reinterpret_cast<const half8*>(lds + (wo[j] ^ ((ks + 1) << 5)));
 #pragma unroll
@@ -218,8 +259,14 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #else
     if (n_main > 0) {
 #endif
-        issue_halo(r_src, Cin, c_begin * C16_KC, 0);
+        issue_main_halo(c_begin, 0);
         issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)(c_begin * C16_KC), 0);
+        if (fuse_gn) {
+            load_gn(c_begin);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) act_group(gi, 0);
+        }
     }
 #pragma unroll 1
 #ifdef DDNM_P16_NO_MAIN
@@ -233,11 +280,19 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll 1
         for (int tap = 0; tap < TAPS; ++tap) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef DDNM_P16_NO_SYNC
             __syncthreads();           // this step's tiles have landed (every wave's), the other buffers are free
+#endif
             if (tap + 1 < TAPS) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
             else if (more) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((c + 1) * C16_KC), wb ^ 1);
-            if (tap == 0 && more) issue_halo(r_src, Cin, (c + 1) * C16_KC, hb ^ 1);
+            if (tap == 0 && more) {
+                issue_main_halo(c + 1, hb ^ 1);
+                if (fuse_gn) load_gn(c + 1);
+            }
             mfma_step(toff, hb, wb);
+            // the next chunk's halo landed before this step's barrier (vmcnt(0) at tap 1): activate one 8-row piece per
+            // tap while this step's MFMAs drain
+            if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) act_group(tap - 1, hb ^ 1);
             wb ^= 1;
             if (++kx == 3) { kx = 0; toff += HWd - 2; } else { ++toff; }
         }
@@ -591,6 +646,9 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
             return DDNM_E_SHAPE;
     }
     if (d->stats_out && pl.stats_tiles <= 0) return DDNM_E_SHAPE;
+    if ((d->gn_scale == nullptr) != (d->gn_shift == nullptr)) return DDNM_E_BADARG;
+    if (d->gn_scale && pl.taps != 9) return DDNM_E_SHAPE;          // 1x1 launches take an already activated operand
+    if (d->src1 && (d->C0 <= 0 || d->C0 >= d->Cin || d->C0 % C16_KC)) return DDNM_E_SHAPE;
     if (pl.ksplit > 1) {
         const int64_t need = (int64_t)pl.ksplit * d->B * d->H * d->W * d->Cout;
         if (!d->workspace || d->workspace_floats < need) return DDNM_E_BADARG;

@@ -120,21 +120,46 @@ extern "C" int ddnm_avgpool2_nhwc_f32(const float* in, const float* gn_scale, co
 }
 
 // emb[b][:] += table[idx[b]][:]   (nn.Embedding lookup of the class label, guided_diffusion/unet.py:651-653)
+// A label outside [0, rows) never reads the table: the row is poisoned with NaN instead (torch.nn.Embedding would
+// raise; a kernel cannot, and a host-side check would cost a device->host sync per forward) -- loud, not silent.
 __global__ void embedding_add_kernel(float* __restrict__ emb, const float* __restrict__ table,
-                                     const int64_t* __restrict__ idx, int D) {
+                                     const int64_t* __restrict__ idx, int D, int rows) {
     const int b = blockIdx.x;
-    const float* row = table + (size_t)idx[b] * D;
-    for (int i = threadIdx.x; i < D; i += blockDim.x) emb[(size_t)b * D + i] += row[i];
+    const int64_t r = idx[b];
+    const bool ok = r >= 0 && r < rows;
+    const float* row = table + (size_t)(ok ? r : 0) * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x)
+        emb[(size_t)b * D + i] = ok ? emb[(size_t)b * D + i] + row[i] : __builtin_nanf("");
 }
 
 extern "C" int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, int32_t B, int32_t D,
-                                      void* stream) {
-    if (!emb || !table || !idx || B <= 0 || D <= 0) return DDNM_E_BADARG;
-    DDNM_LAUNCH(embedding_add_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, table, idx, D);
+                                      int32_t rows, void* stream) {
+    if (!emb || !table || !idx || B <= 0 || D <= 0 || rows <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(embedding_add_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, table, idx, D, rows);
     return 0;
 }
 
-extern "C" int ddnm_version(void) { return 1; }
+// ABI version: bumped whenever a descriptor struct or a prototype of include/ddnm_hip.h changes
+// (2: ddnm_conv16_desc and the fp16-activation entry points, ddnm_build_digest, ddnm_sizeof).
+extern "C" int ddnm_version(void) { return 2; }
+
+// sha256 of the sources + flags this binary was compiled from (ddnm_amd/build.py passes it with -D); the loader
+// (ddnm_amd/_lib.py) compares it with the digest of the sources next to it and refuses a stale binary.
+#ifndef DDNM_BUILD_DIGEST
+#define DDNM_BUILD_DIGEST "unstamped"
+#endif
+extern "C" const char* ddnm_build_digest(void) { return DDNM_BUILD_DIGEST; }
+
+// sizeof() of the descriptor structs as this binary sees them: 0 conv_desc, 1 gemm_desc, 2 conv16_desc, 3 step_scalars
+extern "C" int ddnm_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(ddnm_conv_desc);
+        case 1: return (int)sizeof(ddnm_gemm_desc);
+        case 2: return (int)sizeof(ddnm_conv16_desc);
+        case 3: return (int)sizeof(ddnm_step_scalars);
+        default: return -1;
+    }
+}
 
 extern "C" const char* ddnm_error_string(int code) {
     if (code == 0) return "success";

@@ -21,7 +21,8 @@ def init(backend=None):
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # "nccl" is RCCL on ROCm; DDNM_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box)
+            backend = os.environ.get("DDNM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -61,13 +62,22 @@ def gather_images(x_local, n_total=None):
     pad = x_local
     if x_local.shape[0] < max_n:     # all_gather needs equal shapes
         pad = torch.cat([x_local, x_local.new_zeros(max_n - x_local.shape[0], *x_local.shape[1:])], 0)
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad.contiguous())
+    pad = pad.contiguous()
+    if dist.get_backend() == "gloo" and pad.is_cuda:      # gloo gathers host tensors only
+        host = pad.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host)
+        parts = [p.to(pad.device) for p in parts]
+    else:
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
 
 
 def reduce_sum(value, device):
     """Scalar sum over ranks (PSNR accumulation, diffusion.py:602)."""
+    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

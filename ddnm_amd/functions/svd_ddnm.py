@@ -20,6 +20,11 @@ prediction (:72-74).
 `noise` (optional) is an explicit tape: tensor [n_iters, B, 3, H, W] or a list of
 tensors, consumed one per loop iteration.  Without it, noise is drawn from the
 device generator like the reference's `torch.randn_like`.
+
+`return_cpu` (default True) matches the reference, which hands back CPU tensors
+(`xs[-1]`, `x0_preds[-1]` were `.to('cpu')`, svd_ddnm.py:67-68,76-78); the runner, the
+benchmark and the parity tests pass False and keep the result in HBM.  `record(k, name, tensor)`
+is an optional probe called with the device tensors `x0_t` / `xt_next` after iteration k.
 """
 import torch
 
@@ -97,7 +102,14 @@ def _noise_source(noise, like):
     return take
 
 
-def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, config=None, noise=None):
+def _finish(xt, x0_t, return_cpu):
+    if return_cpu:
+        return [xt.to("cpu")], [x0_t.to("cpu")]
+    return [xt], [x0_t]
+
+
+def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, config=None, noise=None, return_cpu=True,
+                   record=None):
     if not x.is_cuda:
         raise RuntimeError("ddnm_amd.ddnm_diffusion runs on the GPU only (no CPU fallback); got a CPU tensor")
     skip = config.diffusion.num_diffusion_timesteps // config.time_travel.T_sampling
@@ -109,6 +121,8 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
     y = y.reshape(n, -1).float().contiguous()
     draw = _noise_source(noise, x)
     fused = isinstance(A_funcs, A_functions)
+    if hasattr(A_funcs, "begin_run"):
+        A_funcs.begin_run(y)           # per-run constants of the operator (e.g. A^+ y); never cached across runs
 
     xt = x
     x0_t = torch.empty_like(x)
@@ -143,10 +157,14 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                 assert have_x0
                 ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
-    return [xt], [x0_t]
+            if record is not None:
+                record(k, "x0_t", x0_t)
+                record(k, "xt_next", xt)
+    return _finish(xt, x0_t, return_cpu)
 
 
-def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, classes=None, config=None, noise=None):
+def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, classes=None, config=None, noise=None,
+                        return_cpu=True):
     """DDNM+ for noisy measurements: drop-in for `functions/svd_ddnm.py::ddnm_plus_diffusion` (:80-164).
 
       x0|t  = (x_t - eps*sqrt(1-abar_t)) / sqrt(abar_t)                                  (Eq. 12)
@@ -200,4 +218,4 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                 assert have_x0
                 ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
-    return [xt], [x0_t]
+    return _finish(xt, x0_t, return_cpu)

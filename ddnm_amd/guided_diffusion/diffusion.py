@@ -10,8 +10,10 @@ Deliberate differences at the boundary (not in the results):
   * checkpoints are never downloaded (no network): `exp/logs/celeba/celeba_hq.ckpt` must exist,
     or `DDNM_RANDOM_WEIGHTS=1` selects seeded random weights of the same architecture;
   * images are read/written with PIL (torchvision is not required);
-  * multi-GPU is one process per GPU with the dataset sharded by index and one RCCL gather of the
-    PSNR sum (ddnm_amd.dist), not `torch.nn.DataParallel` (:140,164).
+  * multi-GPU is one process per GPU (ddnm_amd.dist), not `torch.nn.DataParallel` (:140,164): every rank sees the
+    same batches, restores the images [lo, hi) of each batch (its slice of x_T and of the per-step noise, both drawn
+    for the WHOLE batch from a per-batch generator so the result does not depend on the number of ranks), and the
+    restored shards meet in ONE RCCL all_gather per batch; rank 0 writes the PNGs and reports the PSNR.
 """
 import os
 import random
@@ -52,12 +54,13 @@ IMG_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".webp")
 
 
 class ImageFolder(data.Dataset):
-    """torchvision.datasets.ImageFolder + Resize([S,S]) + ToTensor (datasets/__init__.py:144-150):
-    classes = sorted sub-directories, files sorted inside each."""
+    """torchvision.datasets.ImageFolder + ToTensor: classes = sorted sub-directories, files sorted inside each.
+    transform "resize": Resize([S,S]) bilinear (datasets/__init__.py:138-150, CelebA_HQ / FFHQ);
+    transform "center_crop_arr": the guided-diffusion crop (`out_of_dist` LSUN / ImageNet folders, :113-119,177-183)."""
 
-    def __init__(self, root, image_size):
+    def __init__(self, root, image_size, transform="resize"):
         from PIL import Image  # noqa: F401
-        self.size = image_size
+        self.size, self.transform = image_size, transform
         self.items = []
         classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
         for ci, c in enumerate(classes):
@@ -74,8 +77,12 @@ class ImageFolder(data.Dataset):
     def __getitem__(self, i):
         from PIL import Image
         path, cls = self.items[i]
-        img = Image.open(path).convert("RGB").resize((self.size, self.size), Image.BILINEAR)
-        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+        img = Image.open(path).convert("RGB")
+        if self.transform == "center_crop_arr":
+            arr = center_crop_arr(img, self.size)
+        else:
+            arr = np.asarray(img.resize((self.size, self.size), Image.BILINEAR), dtype=np.uint8)
+        x = torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0)
         return x, cls
 
 
@@ -92,17 +99,28 @@ def center_crop_arr(pil_image, image_size=256):
     return arr[cy:cy + image_size, cx:cx + image_size]
 
 
+def center_crop_long_edge(pil_image):
+    """datasets/imagenet_subset.py:5-23 (`CenterCropLongEdge`): torchvision's center_crop to min(w, h) -- the offsets
+    are int(round((dim - s) / 2.0)) like torchvision.transforms.functional.center_crop."""
+    w, h = pil_image.size
+    s = min(w, h)
+    left, top = int(round((w - s) / 2.0)), int(round((h - s) / 2.0))
+    return pil_image.crop((left, top, left + s, top + s))
+
+
 class ImageList(data.Dataset):
-    """datasets/imagenet_subset.py::ImageDataset with normalize=False: list file of '<name> <label>'."""
+    """datasets/imagenet_subset.py::ImageDataset(normalize=False) (:48-103), what `subset_1k: true` of the ImageNet
+    configs selects (datasets/__init__.py:169-175): list file of '<name> <label>' (label -1 when absent),
+    CenterCropLongEdge + Resize(image_size) (bilinear) + ToTensor."""
 
     def __init__(self, root, list_file, image_size):
         self.root, self.size = root, image_size
         self.items = []
         with open(list_file) as f:
             for line in f:
-                parts = line.split()
+                parts = line.rstrip().split()
                 if parts:
-                    self.items.append((parts[0], int(parts[1]) if len(parts) > 1 else 0))
+                    self.items.append((parts[0], int(parts[1]) if len(parts) == 2 else -1))
 
     def __len__(self):
         return len(self.items)
@@ -110,8 +128,10 @@ class ImageList(data.Dataset):
     def __getitem__(self, i):
         from PIL import Image
         name, label = self.items[i]
-        arr = center_crop_arr(Image.open(os.path.join(self.root, name)).convert("RGB"), self.size)
-        x = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
+        with open(self.root + "/" + name, "rb") as f:
+            img = Image.open(f).convert("RGB")
+        img = center_crop_long_edge(img).resize((self.size, self.size), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
         return x, label
 
 
@@ -145,6 +165,52 @@ def data_transform(config, X):
     raise NotImplementedError("only rescaled data is on the DDNM hot path")
 
 
+# functions/ckpt_util.py:15-24 (EMA checkpoints of the DDIM authors; `church_outdoor` -> `church`, :56-57)
+LSUN_CKPT = {"bedroom": "ema_diffusion_lsun_bedroom_model/model-2388000.ckpt",
+             "cat": "ema_diffusion_lsun_cat_model/model-1761000.ckpt",
+             "church": "ema_diffusion_lsun_church_model/model-4432000.ckpt"}
+
+
+def simple_checkpoint_path(config, exp):
+    """Checkpoint of a `model.type: simple` config (guided_diffusion/diffusion.py:115-136): celeba_hq ->
+    exp/logs/celeba/celeba_hq.ckpt; LSUN category -> the `ema_lsun_<category>` file get_ckpt_path resolves under
+    $XDG_CACHE_HOME or exp/logs/ + diffusion_models_converted/ (ckpt_util.py:55-66).  Nothing is downloaded here."""
+    ds = config.data.dataset
+    if ds == "CelebA_HQ":
+        return os.path.join(exp, "logs/celeba/celeba_hq.ckpt")
+    if ds == "LSUN":
+        cat = str(config.data.category).replace("church_outdoor", "church")
+        if cat not in LSUN_CKPT:
+            raise ValueError(f"no checkpoint known for LSUN category {config.data.category!r}")
+        cachedir = os.environ.get("XDG_CACHE_HOME", os.path.join(exp, "logs/"))
+        return os.path.join(cachedir, "diffusion_models_converted", LSUN_CKPT[cat])
+    raise ValueError(f"no checkpoint family for dataset {ds!r} with model.type=simple")   # CIFAR10 is not a DDNM config
+
+
+class BatchNoise:
+    """Noise of one loader batch, independent of how the batch is sharded: x_T and the tensor of loop iteration k are
+    drawn for ALL `n` images from a generator seeded by (seed, batch index) -- in a fixed order -- and sliced to
+    [lo, hi).  Indexing is sequential (`tape[k]` for k = 0, 1, ...), which is how `ddnm_diffusion(noise=...)` reads it."""
+
+    def __init__(self, seed, batch_index, n, shape, lo, hi, device):
+        self.g = torch.Generator(device=device)
+        self.g.manual_seed((int(seed) * 1000003 + int(batch_index)) % (2 ** 63 - 1))
+        self.full, self.lo, self.hi, self.device = (n,) + tuple(shape), lo, hi, device
+        self.next_k = 0
+
+    def draw(self, shape=None):
+        return torch.randn(self.full if shape is None else shape, generator=self.g, device=self.device)
+
+    def x_T(self):
+        return self.draw()[self.lo:self.hi].contiguous()
+
+    def __getitem__(self, k):
+        if k != self.next_k:
+            raise IndexError(f"BatchNoise is a sequential tape: asked for {k}, expected {self.next_k}")
+        self.next_k += 1
+        return self.draw()[self.lo:self.hi].contiguous()
+
+
 class Diffusion(object):
     def __init__(self, args, config, device=None):
         self.args, self.config = args, config
@@ -164,10 +230,8 @@ class Diffusion(object):
     def _build_model(self):
         cfg = self.config
         if cfg.model.type == "simple":
-            if cfg.data.dataset != "CelebA_HQ":
-                raise ValueError("only the celeba_hq checkpoint family is wired for model.type=simple")
             model = Model(cfg, device=self.device)
-            ckpt = os.path.join(self.args.exp, "logs/celeba/celeba_hq.ckpt")
+            ckpt = simple_checkpoint_path(cfg, self.args.exp)
             if os.path.exists(ckpt):
                 model.load_state_dict(torch.load(ckpt, map_location="cpu"))
             elif os.environ.get("DDNM_RANDOM_WEIGHTS") == "1":
@@ -239,18 +303,35 @@ class Diffusion(object):
             n = int(str(args.path_y).split(":")[1]) if ":" in str(args.path_y) else config.sampling.batch_size
             ds = SyntheticImages(n, config.data.image_size, args.seed)
         elif config.data.dataset in ("CelebA_HQ", "FFHQ"):
-            ds = ImageFolder(os.path.join(args.exp, "datasets", args.path_y), config.data.image_size)
-            # datasets/__init__.py:152-167: indices shuffled with numpy seed 2019, all of them are "test"
-            idx = list(range(len(ds)))
-            state = np.random.get_state()
-            np.random.seed(2019)
-            np.random.shuffle(idx)
-            np.random.set_state(state)
-            ds = data.Subset(ds, idx)
+            if getattr(config.data, "out_of_dist", False):          # datasets/__init__.py:137-143
+                ds = ImageFolder(os.path.join(args.exp, "datasets", "ood_celeba"), config.data.image_size)
+            else:
+                ds = ImageFolder(os.path.join(args.exp, "datasets", args.path_y), config.data.image_size)
+                # datasets/__init__.py:152-167: indices shuffled with numpy seed 2019, all of them are "test"
+                idx = list(range(len(ds)))
+                state = np.random.get_state()
+                np.random.seed(2019)
+                np.random.shuffle(idx)
+                np.random.set_state(state)
+                ds = data.Subset(ds, idx)
+        elif config.data.dataset == "LSUN":
+            if getattr(config.data, "out_of_dist", False):          # datasets/__init__.py:112-119
+                ds = ImageFolder(os.path.join(args.exp, "datasets", f"ood_{config.data.category}"), config.data.image_size,
+                                 transform="center_crop_arr")
+            else:
+                raise NotImplementedError("the LSUN lmdb validation sets (datasets/__init__.py:120-134) need the `lmdb` "
+                                          "package; use out_of_dist: true with an image folder exp/datasets/ood_<category>")
         elif config.data.dataset == "ImageNet":
-            # datasets/__init__.py:166-175: exp/imagenet_val_1k.txt lists "<file> <label>" under exp/datasets/imagenet/imagenet
-            ds = ImageList(os.path.join(args.exp, "datasets", "imagenet", "imagenet"),
-                           os.path.join(args.exp, "imagenet_val_1k.txt"), config.data.image_size)
+            if getattr(config.data, "subset_1k", False):
+                # datasets/__init__.py:169-175: exp/imagenet_val_1k.txt lists "<file> <label>" under exp/datasets/imagenet/imagenet
+                ds = ImageList(os.path.join(args.exp, "datasets", "imagenet", "imagenet"),
+                               os.path.join(args.exp, "imagenet_val_1k.txt"), config.data.image_size)
+            elif getattr(config.data, "out_of_dist", False):        # :176-183
+                ds = ImageFolder(os.path.join(args.exp, "datasets", "ood"), config.data.image_size,
+                                 transform="center_crop_arr")
+            else:
+                raise NotImplementedError("torchvision.datasets.ImageNet(split='val') (datasets/__init__.py:184-190) is "
+                                          "not rebuilt here; use subset_1k: true or out_of_dist: true")
         else:
             raise NotImplementedError(f"dataset {config.data.dataset}")
         if args.subset_start >= 0 and args.subset_end > 0:
@@ -281,47 +362,57 @@ class Diffusion(object):
         print(f"Start from {args.subset_start}")
         idx_so_far = args.subset_start
         psnr_sum, n_done = 0.0, 0
-        os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
+        C, S = config.data.channels, config.data.image_size
+        if rank == 0:
+            os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
         for bi, (x_orig, classes) in enumerate(loader):
-            if bi % world != rank:               # batches are dealt round-robin to the ranks
-                idx_so_far += x_orig.shape[0]
-                continue
+            # every rank sees the same batch (same loader seed); rank r restores images [lo, hi) of it
             x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
-            y = A_funcs.A(x_orig)
-            b = y.shape[0]
+            b = x_orig.shape[0]
+            lo, hi = ddist.shard_range(b, rank, world)
+            noise = BatchNoise(args.seed, bi, b, (C, S, S), lo, hi, self.device)
+            y = A_funcs.A(x_orig)                # the whole batch: operators are cheap, and rank 0 needs A^+ y of all
             if args.add_noise:
-                y = y + torch.randn_like(y) * sigma_y
-            Apy = A_funcs.A_pinv(y).view(b, config.data.channels, config.data.image_size, config.data.image_size)
-            if args.deg[:6] == "deblur":
-                Apy = y.view(b, config.data.channels, config.data.image_size, config.data.image_size)
-            elif args.deg == "colorization":
-                Apy = y.view(b, 1, config.data.image_size, config.data.image_size).repeat(1, 3, 1, 1)
-            elif args.deg == "inpainting":
-                Apy = Apy + A_funcs.A_pinv(A_funcs.A(torch.ones_like(Apy))).reshape(*Apy.shape) - 1
-            for i in range(b):
-                save_image(ops.finalize_psnr(Apy[i:i + 1].contiguous())[0][0],
-                           os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far + i}.png"))
-                save_image(ops.finalize_psnr(x_orig[i:i + 1])[0][0],
-                           os.path.join(args.image_folder, f"Apy/orig_{idx_so_far + i}.png"))
-            x = torch.randn(b, config.data.channels, config.data.image_size, config.data.image_size,
-                            device=self.device)
-            with torch.no_grad():
-                if sigma_y == 0.0:       # noise-free case, DDNM (diffusion.py:587-588)
-                    xs, _ = ddnm_diffusion(x, model, self.betas, args.eta, A_funcs, y, cls_fn=cls_fn, classes=classes,
-                                           config=config)
-                else:                    # noisy case, DDNM+ (:589-590)
-                    xs, _ = ddnm_plus_diffusion(x, model, self.betas, args.eta, A_funcs, y, sigma_y, cls_fn=cls_fn,
-                                                classes=classes, config=config)
-            img, psnr = ops.finalize_psnr(xs[0], x_orig)
-            for j in range(b):
-                save_image(img[j], os.path.join(args.image_folder, f"{idx_so_far + j}_{0}.png"))
-            psnr_sum += float(psnr.sum())
-            n_done += b
+                y = y + noise.draw(tuple(y.shape)) * sigma_y
+            if rank == 0:
+                Apy = A_funcs.A_pinv(y).view(b, C, S, S)
+                if args.deg[:6] == "deblur":
+                    Apy = y.view(b, C, S, S)
+                elif args.deg == "colorization":
+                    Apy = y.view(b, 1, S, S).repeat(1, 3, 1, 1)
+                elif args.deg == "inpainting":
+                    Apy = Apy + A_funcs.A_pinv(A_funcs.A(torch.ones_like(Apy))).reshape(*Apy.shape) - 1
+                for i in range(b):
+                    save_image(ops.finalize_psnr(Apy[i:i + 1].contiguous())[0][0],
+                               os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far + i}.png"))
+                    save_image(ops.finalize_psnr(x_orig[i:i + 1])[0][0],
+                               os.path.join(args.image_folder, f"Apy/orig_{idx_so_far + i}.png"))
+            x = noise.x_T()
+            if hi > lo:
+                y_loc = y.reshape(b, -1)[lo:hi].contiguous()
+                with torch.no_grad():
+                    if sigma_y == 0.0:       # noise-free case, DDNM (diffusion.py:587-588)
+                        xs, _ = ddnm_diffusion(x, model, self.betas, args.eta, A_funcs, y_loc, cls_fn=cls_fn,
+                                               classes=classes, config=config, noise=noise, return_cpu=False)
+                    else:                    # noisy case, DDNM+ (:589-590)
+                        xs, _ = ddnm_plus_diffusion(x, model, self.betas, args.eta, A_funcs, y_loc, sigma_y, cls_fn=cls_fn,
+                                                    classes=classes, config=config, noise=noise, return_cpu=False)
+                x_loc = xs[0]
+            else:
+                x_loc = x                    # empty shard (fewer images than ranks): takes part in the gather only
+            x_all = ddist.gather_images(x_loc, n_total=b)      # the path's single collective (one per batch)
+            if rank == 0:
+                img, psnr = ops.finalize_psnr(x_all.contiguous(), x_orig)
+                for j in range(b):
+                    save_image(img[j], os.path.join(args.image_folder, f"{idx_so_far + j}_{0}.png"))
+                psnr_sum += float(psnr.sum())
+                n_done += b
+                print("PSNR: %.2f" % (psnr_sum / n_done))
             idx_so_far += b
-            print("PSNR: %.2f" % (psnr_sum / n_done))
-        psnr_sum, n_done = ddist.reduce_sum(psnr_sum, self.device), ddist.reduce_sum(n_done, self.device)
-        print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
-        print("Number of samples: %d" % n_done)
+        if rank == 0:
+            print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
+            print("Number of samples: %d" % n_done)
+        ddist.barrier()
         return psnr_sum / max(n_done, 1)
 
     # ------------------------------------------------------------------ simplified path (diffusion.py:211-415)
@@ -350,14 +441,18 @@ class Diffusion(object):
         op = self._simplified_operator()
         args.sigma_y = 2 * args.sigma_y
         sigma_y = args.sigma_y
+        rank, _, world = ddist.env_world()
         print(f"Start from {args.subset_start}")
         idx_so_far = args.subset_start
         psnr_sum, n_done = 0.0, 0
         os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
-        for x_orig, classes in loader:
-            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
+        for bi, (x_orig, classes) in enumerate(loader):
             if config.sampling.batch_size != 1:
                 raise ValueError("please change the config file to set batch size as 1")
+            if bi % world != rank:               # batch size is 1 here (:308-309): whole images are dealt round-robin
+                idx_so_far += x_orig.shape[0]
+                continue
+            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
             y = op.A(x_orig)
             Apy = op.A_pinv(y).view(*x_orig.shape)
             save_image(ops.finalize_psnr(Apy.contiguous())[0][0], os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far}.png"))
@@ -372,8 +467,10 @@ class Diffusion(object):
             idx_so_far += y.shape[0]
             n_done += y.shape[0]
             print("PSNR: %.2f" % (psnr_sum / n_done))
-        print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
-        print("Number of samples: %d" % n_done)
+        psnr_sum, n_done = ddist.reduce_sum(psnr_sum, self.device), int(ddist.reduce_sum(n_done, self.device))
+        if rank == 0:
+            print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
+            print("Number of samples: %d" % n_done)
         return psnr_sum / max(n_done, 1)
 
 
@@ -389,6 +486,8 @@ def simplified_loop(x, model, betas, eta, op, y, sigma_y, config, noise=None):
     xt = x.float().contiguous()
     x0_t = torch.empty_like(xt)
     bufs = [torch.empty_like(xt), torch.empty_like(xt)]
+    if hasattr(op, "begin_run"):
+        op.begin_run(y)
     with torch.no_grad():
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip

@@ -384,16 +384,19 @@ class UNetModel:
 
     # ------------------------------------------------------------------ fp16-activation forward (csrc/conv16.hip)
     def _conv3x3_16(self, key, cout, x0, x1, gn, silu=True, **kw):
-        """3x3 convolution of act(concat(x0, x1)): activated operand written once (ops.gn_apply16), then ddnm_conv16;
-        images too small for a pixel tile (8x8) go through im2col + one GEMM with K = 9*Cin."""
+        """3x3 convolution of act(concat(x0, x1)) on ddnm_conv16 with the GroupNorm affine + swish and the concat fused
+        into its loader (DDNM_H16_PREPASS=1: operand written once by ops.gn_apply16 instead); images too small for a
+        pixel tile (8x8) go through im2col + one GEMM with K = 9*Cin."""
         w16 = self.w[key + ".h16"]
         B, H, W, _ = x0.t.shape
         cin = x0.t.shape[3] + (0 if x1 is None else x1.t.shape[3])
         ups = kw.get("ups", False)
         Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
         if ops.conv16_supported(B, Ho, Wo, cin, cout, 3, ups=ups):
-            a = x0.t if (gn is None and x1 is None) else ops.gn_apply16(x0, x1, gn, silu)
-            return ops.conv16(a, w16, cout, 3, **kw)
+            if os.environ.get("DDNM_H16_PREPASS") == "1":
+                a = x0.t if (gn is None and x1 is None) else ops.gn_apply16(x0, x1, gn, silu)
+                return ops.conv16(a, w16, cout, 3, **kw)
+            return ops.conv16(x0, w16, cout, 3, src1=x1, gn=gn, gn_silu=silu, **kw)
         assert not ups and kw.get("skip") is None
         col = ops.im2col16(x0, x1, gn, silu)
         return ops.conv16(col, w16.reshape(w16.shape[0], 1, -1), cout, 1, **kw)

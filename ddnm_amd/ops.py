@@ -275,11 +275,18 @@ def pack_conv_weight16(w, cin_pad=None):
     return out.contiguous()
 
 
-def _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups):
+def _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups, src1=None, gn=None,
+                 gn_silu=True):
     B = src.shape[0]
     d = Conv16Desc()
     d.src, d.weight, d.bias, d.res = _p(_f16c(src, "src")), _p(_f16c(weight, "weight")), _p(bias), _p(res)
-    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, W, src.shape[-1], cout, ksize
+    cin = src.shape[-1]
+    if src1 is not None:
+        d.src1, d.C0 = _p(_f16c(src1, "src1")), cin
+        cin += src1.shape[-1]
+    if gn is not None:
+        d.gn_scale, d.gn_shift, d.gn_silu = _p(gn[0]), _p(gn[1]), int(gn_silu)
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, W, cin, cout, ksize
     d.ups, d.res_ups = int(ups), int(res_ups)
     if skip is not None:
         s0, s1 = skip
@@ -294,18 +301,20 @@ def conv16_supported(B, H, W, cin, cout, ksize, ups=False):
     return _lib.lib().ddnm_conv16_supported(ctypes.byref(d)) == 1
 
 
-def conv16(src, weight, cout, ksize, *, bias=None, res=None, res_ups=False, ups=False, skip=None, skip_weight=None,
-           emit_stats=True, out=None):
-    """fp16 NHWC convolution of the `use_fp16` torso (include/ddnm_hip.h::ddnm_conv16_desc): `src` is the already
-    activated fp16 operand [B,Hs,Ws,Cin]; returns an `Act` whose tensor is fp16 [B,H,W,cout] and whose GroupNorm
+def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=None, res=None, res_ups=False, ups=False,
+           skip=None, skip_weight=None, emit_stats=True, out=None):
+    """fp16 NHWC convolution of the `use_fp16` torso (include/ddnm_hip.h::ddnm_conv16_desc).  The operand is
+    concat_c(src, src1) [B,Hs,Ws,Cin] fp16: raw with `gn` = (scale, shift) (3x3 only: GroupNorm affine + swish fused,
+    applied in LDS) or already activated.  Returns an `Act` whose tensor is fp16 [B,H,W,cout] and whose GroupNorm
     partials (when the launch can emit them) describe exactly those rounded values."""
     src = src.t if isinstance(src, Act) else src
+    src1 = src1.t if isinstance(src1, Act) else src1
     res = res.t if isinstance(res, Act) else res
     B, Hs, Ws, _ = src.shape
     H, W = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     if skip is not None:
         skip = tuple(None if s is None else (s.t if isinstance(s, Act) else s) for s in skip)
-    d = _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups)
+    d = _conv16_desc(src, weight, cout, ksize, H, W, ups, skip, skip_weight, bias, res, res_ups, src1, gn, gn_silu)
     L = _lib.lib()
     if out is None:
         out = torch.empty(B, H, W, cout, dtype=torch.float16, device=src.device)
@@ -522,8 +531,10 @@ def avgpool2_nhwc(x, gn=None, silu=False):
 
 def embedding_add_(emb, table, idx):
     idx = idx.to(device=emb.device, dtype=torch.int64).contiguous()
-    check(_lib.lib().ddnm_embedding_add_f32(_p(emb), _p(table), _p(idx), emb.shape[0], emb.shape[1], _stream()),
-          "ddnm_embedding_add_f32")
+    if idx.numel() != emb.shape[0]:
+        raise ValueError("embedding_add_: one index per row expected")
+    check(_lib.lib().ddnm_embedding_add_f32(_p(emb), _p(table), _p(idx), emb.shape[0], emb.shape[1], table.shape[0],
+                                            _stream()), "ddnm_embedding_add_f32")
     return emb
 
 

@@ -28,7 +28,10 @@ extern "C" {
 #define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
 #define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
 
-int ddnm_version(void);                 /* ABI version, currently 1 */
+int ddnm_version(void);                 /* ABI version, currently 2 (bumped on every struct / prototype change) */
+const char* ddnm_build_digest(void);    /* sha256 of the sources + flags this binary was built from (build.py) */
+int ddnm_sizeof(int which);             /* sizeof of 0: ddnm_conv_desc, 1: ddnm_gemm_desc, 2: ddnm_conv16_desc,
+                                           3: ddnm_step_scalars as compiled into the binary (-1: unknown index) */
 const char* ddnm_error_string(int code);
 
 /* ------------------------------------------------------------------------- *
@@ -128,12 +131,14 @@ int ddnm_conv1x1_f16_stats_tiles(const ddnm_conv_desc* d);
  * `up=True` blocks) and the GroupNorm partials of the output.
  *   out[b,y,x,n] = fp16( bias[n] + res[b,y,x,n] + sum W[n,ky,kx,c] * src[b, y+ky-1, x+kx-1, c]
  *                        + sum W_skip[n,c] * concat_c(skip0, skip1)[b,y,x,c] )
- * `src` is ALREADY normalised / activated (ddnm_gn_apply_h16), zero padded by the kernel.
+ * act(v) = silu?(v*gn_scale[b,c] + gn_shift[b,c]) when gn_scale != NULL (3x3 only; applied inside LDS after the
+ * LDS-DMA, zero padding AFTER act like the reference), identity otherwise (operand already activated by
+ * ddnm_gn_apply_h16).  The operand may be the channel concat of `src` (C0 channels) and `src1`.
  * Needs Cin % 64 == 0, Cout % 64 == 0; 3x3: W % 16 == 0 and H*W % 128 == 0 (smaller images: ddnm_im2col3x3_h16 +
  * ksize 1).  ksize 1 treats src as a flat [B*H*W][Cin] matrix (any row count).
  * ------------------------------------------------------------------------- */
 typedef struct ddnm_conv16_desc {
-    const void* src;          /* fp16 NHWC [B][Hs][Ws][Cin]; Hs = H/2 when ups */
+    const void* src;          /* fp16 NHWC [B][Hs][Ws][C0] (C0 = Cin without src1); Hs = H/2 when ups */
     const void* weight;       /* fp16 packed [ceil(Cout/256)*256][ksize*ksize][Cin] (O,ky,kx,I) */
     const float* bias;        /* [Cout] or NULL */
     const void* res;          /* fp16 NHWC [B][H][W][Cout] ([B][H/2][W/2][Cout] when res_ups) or NULL */
@@ -150,6 +155,11 @@ typedef struct ddnm_conv16_desc {
     int32_t ksize;            /* 1 or 3 */
     int32_t ups, res_ups;
     int32_t SC0, SC1;
+    const void* src1;         /* fp16 NHWC [B][Hs][Ws][Cin-C0] second tensor of the concat or NULL (torch.cat, unet.py:661) */
+    const float* gn_scale;    /* [B][Cin] fp32 or NULL: fused GroupNorm(+FiLM) affine of the operand (3x3 only) */
+    const float* gn_shift;    /* [B][Cin] (required iff gn_scale) */
+    int32_t C0;               /* channels of `src` when src1 != NULL (C0 % 64 == 0) */
+    int32_t gn_silu;          /* 1: swish after the affine */
     int32_t out_nchw_f32;     /* 1: the network's output convolution (unet.py:627-631, `.type(x.dtype)` :664): 3x3,
                                  Cout <= 32 (weight packed to 32 rows or more), fp32 NCHW result, no res / skip / stats */
     int32_t reserved;
@@ -281,8 +291,10 @@ int ddnm_timestep_embedding_f32(const float* t, const float* freq, float* emb, i
  * `down=True` ResBlock (guided_diffusion/unet.py:133-140,237-242).  in is [B][2Ho][2Wo][C]. */
 int ddnm_avgpool2_nhwc_f32(const float* in, const float* gn_scale, const float* gn_shift, int32_t silu, float* out,
                            int32_t B, int32_t Ho, int32_t Wo, int32_t C, void* stream);
-/* emb[b][:] += table[idx[b]][:]  (class-label embedding, guided_diffusion/unet.py:651-653); idx is int64. */
-int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, int32_t B, int32_t D, void* stream);
+/* emb[b][:] += table[idx[b]][:]  (class-label embedding, guided_diffusion/unet.py:651-653); idx is int64; `rows` =
+ * rows of `table`: a label outside [0, rows) poisons its row with NaN instead of reading out of bounds. */
+int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, int32_t B, int32_t D, int32_t rows,
+                           void* stream);
 
 /* NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad], channels >= C zero filled. */
 int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t Cpad,

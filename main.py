@@ -76,9 +76,14 @@ def parse_args_and_config(argv=None):
     root.addHandler(handler)
     root.setLevel(level)
 
-    rank = int(os.environ.get("RANK", 0))
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     os.makedirs(os.path.join(args.exp, "image_samples"), exist_ok=True)
     args.image_folder = os.path.join(args.exp, "image_samples", args.image_folder)
+    if os.path.exists(args.image_folder) and not args.ni and world > 1:
+        # the other ranks cannot see rank 0's answer before the process group exists: refuse on EVERY rank instead of
+        # letting rank 0 exit while the others wait in the first barrier
+        print("Output image folder exists; pass --ni to overwrite it in a multi-process run. Program halted.")
+        sys.exit(0)
     if rank == 0:
         if os.path.exists(args.image_folder):
             overwrite = args.ni

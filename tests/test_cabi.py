@@ -37,7 +37,8 @@ def test_prototypes_match_header():
 
 
 def test_version_and_error_strings(lib):
-    assert lib.ddnm_version() == 1
+    from ddnm_amd import _lib
+    assert lib.ddnm_version() == _lib.ABI_VERSION == 2
     assert b"shape" in lib.ddnm_error_string(-2)
     assert b"bad argument" in lib.ddnm_error_string(-1)
     assert lib.ddnm_error_string(0) == b"success"
@@ -57,6 +58,37 @@ def test_struct_layouts_match_header():
     assert names == [f[0] for f in ConvDesc._fields_]
 
 
+def test_conv16_struct_layout_matches_header():
+    from ddnm_amd._lib import Conv16Desc
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct ddnm_conv16_desc"):src.index("} ddnm_conv16_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:const\s+)?(?:void|float|int32_t|int64_t)\s*\*?\s*([A-Za-z0-9_, \*]+);", body)
+    names = [n.strip().lstrip("*") for grp in fields for n in grp.split(",")]
+    assert names == [f[0] for f in Conv16Desc._fields_]
+    assert ctypes.sizeof(Conv16Desc) == 10 * 8 + 8 + 10 * 4 + 3 * 8 + 4 * 4
+
+
+def test_binary_identifies_itself(lib):
+    """The binary carries the digest of the sources it was built from and the sizes of its descriptor structs; the
+    loader refuses a binary that disagrees with the sources next to it (stale .so ran silently)."""
+    from ddnm_amd import _lib, build
+    from ddnm_amd._lib import Conv16Desc, ConvDesc, GemmDesc, StepScalars
+    assert lib.ddnm_build_digest().decode() == build._digest()
+    for i, st in enumerate((ConvDesc, GemmDesc, Conv16Desc, StepScalars)):
+        assert lib.ddnm_sizeof(i) == ctypes.sizeof(st)
+    assert lib.ddnm_sizeof(99) == -1
+
+
+def test_stale_binary_is_refused(monkeypatch):
+    from ddnm_amd import _lib, build
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("DDNM_NO_AUTOBUILD", "1")
+    monkeypatch.setattr(build, "_digest", lambda: "0" * 64)          # pretend the sources changed
+    with pytest.raises(_lib.DDNMHipError, match="different sources"):
+        _lib.lib()
+
+
 def test_argument_validation_without_gpu(lib):
     """Entry points reject bad descriptors before touching the device."""
     from ddnm_amd._lib import ConvDesc, GemmDesc
@@ -71,6 +103,7 @@ def test_argument_validation_without_gpu(lib):
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from ddnm_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("DDNM_NO_AUTOBUILD", "1")
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DDNMHipError):
         _lib.lib()

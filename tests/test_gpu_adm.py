@@ -57,6 +57,9 @@ def test_adm_kernels_film_avgpool_embedding(hip):
     idx = torch.tensor([9, 0, 4])
     got = ops.embedding_add_(emb.clone().cuda(), table.cuda(), idx.cuda()).cpu()
     assert torch.equal(got, emb + table[idx])
+    # a label outside the table never reads out of bounds: its row is poisoned instead (nn.Embedding would raise)
+    bad = ops.embedding_add_(emb.clone().cuda(), table.cuda(), torch.tensor([9, 10, -1]).cuda()).cpu()
+    assert torch.equal(bad[0], emb[0] + table[9]) and bool(torch.isnan(bad[1:]).all())
 
 
 def test_conv_residual_through_upsample(hip):

@@ -95,6 +95,47 @@ def test_conv16_is_deterministic(hip):
     assert torch.equal(a.t, b.t) and torch.equal(a.stats, b.stats)
 
 
+@pytest.mark.parametrize("B,C0,C1,Cout,H,silu,ups,res", [(2, 256, 0, 256, 32, True, False, True),
+                                                         (1, 128, 128, 256, 64, True, False, False),   # concat, 256-pixel tiles
+                                                         (2, 512, 256, 512, 16, True, False, True),    # concat + split-K
+                                                         (1, 256, 0, 256, 64, True, True, False),      # through nearest x2
+                                                         (2, 64, 0, 128, 32, False, False, False)])    # affine only
+def test_conv16_fused_groupnorm_and_concat(hip, B, C0, C1, Cout, H, silu, ups, res):
+    """GroupNorm affine (+ swish) and the channel concat fused into the loader: equals the convolution of the
+    fp16-ROUNDED activated tensor (the same rounding point as the ddnm_gn_apply_h16 pre-pass), zero padding applied
+    after the activation like the reference."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(23)
+    Cin, Hs = C0 + C1, (H // 2 if ups else H)
+    a = torch.randn(B, C0, Hs, Hs, generator=g).half().float()
+    b = torch.randn(B, C1, Hs, Hs, generator=g).half().float() if C1 else None
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).half().float()
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.randn(B, Cin, generator=g), torch.randn(B, Cin, generator=g)
+    r = torch.randn(B, Cout, H, H, generator=g).half().float() if res else None
+    x = a if b is None else torch.cat([a, b], 1)
+    act = x * sc[:, :, None, None] + sh[:, :, None, None]
+    if silu:
+        act = F.silu(act)
+    act = act.half().float()
+    if ups:
+        act = F.interpolate(act, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(act, w, bias, padding=1) + (r if res else 0)
+    gn = (sc.cuda().contiguous(), sh.cuda().contiguous())
+    out = ops.conv16(nhwc16(a), ops.pack_conv_weight16(w.cuda()), Cout, 3, src1=None if b is None else nhwc16(b), gn=gn,
+                     gn_silu=silu, bias=bias.cuda(), res=None if r is None else nhwc16(r), ups=ups)
+    torch.cuda.synchronize()
+    got = out.t.float().cpu().permute(0, 3, 1, 2)
+    assert rel(got, ref) < 8e-4
+    # and bit-identical to the pre-pass route
+    pre = ops.gn_apply16(nhwc16(a), None if b is None else nhwc16(b), gn, silu)
+    out2 = ops.conv16(pre, ops.pack_conv_weight16(w.cuda()), Cout, 3, bias=bias.cuda(), res=None if r is None else nhwc16(r),
+                      ups=ups)
+    torch.cuda.synchronize()
+    assert torch.equal(out.t, out2.t)
+
+
 # ------------------------------------------------------------------ the other kernels of the fp16-activation path
 def test_conv16_out_small_cout(hip):
     """Output convolution: 256 -> 6 channels, fp32 NCHW result (unet.py:627-631)."""

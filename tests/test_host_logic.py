@@ -112,3 +112,69 @@ def test_data_transform_and_beta_schedule():
     assert torch.equal(data_transform(cfg, x), 2 * x - 1.0)
     b = get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02, num_diffusion_timesteps=1000)
     assert b.dtype == np.float64 and torch.equal(torch.from_numpy(b).float(), cases.betas())
+
+
+def test_imagenet_subset_transform_is_center_crop_long_edge_then_bilinear(tmp_path):
+    """`subset_1k: true` reads images like datasets/imagenet_subset.py::ImageDataset(normalize=False): CenterCropLongEdge
+    (torchvision center_crop to min(w, h), offsets int(round((dim - s) / 2.0))) + Resize(S) bilinear + ToTensor -- NOT the
+    guided-diffusion center_crop_arr (box halving + bicubic), which belongs to the out_of_dist folders."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from ddnm_amd.guided_diffusion.diffusion import ImageFolder, ImageList, center_crop_long_edge
+    rng = np.random.RandomState(0)
+    w, h = 301, 200                                     # odd margin: exercises the rounding of the crop offset
+    arr = rng.randint(0, 256, size=(h, w, 3), dtype=np.uint8)
+    os.makedirs(tmp_path / "imgs" / "c0")
+    Image.fromarray(arr).save(tmp_path / "imgs" / "c0" / "a.png")
+    (tmp_path / "list.txt").write_text("c0/a.png 7\nc0/a.png\n")
+    ds = ImageList(str(tmp_path / "imgs"), str(tmp_path / "list.txt"), 64)
+    x, label = ds[0]
+    assert label == 7 and ds[1][1] == -1 and x.shape == (3, 64, 64)
+    left = int(round((w - h) / 2.0))
+    crop = Image.fromarray(arr[:, left:left + h])
+    want = torch.from_numpy(np.asarray(crop.resize((64, 64), Image.BILINEAR))).permute(2, 0, 1).float() / 255
+    assert torch.equal(x, want)
+    assert center_crop_long_edge(Image.fromarray(arr)).size == (h, h)
+    # the out_of_dist folders keep the guided-diffusion transform and differ from it
+    ood = ImageFolder(str(tmp_path / "imgs"), 64, transform="center_crop_arr")[0][0]
+    assert ood.shape == (3, 64, 64) and not torch.equal(ood, x)
+
+
+def test_lsun_checkpoint_names_follow_ckpt_util(tmp_path, monkeypatch):
+    import types
+    from ddnm_amd.guided_diffusion.diffusion import simple_checkpoint_path
+    monkeypatch.delenv("XDG_CACHE_HOME", raising=False)
+    ns = types.SimpleNamespace
+    cfg = lambda ds, cat="": ns(data=ns(dataset=ds, category=cat))      # noqa: E731
+    assert simple_checkpoint_path(cfg("CelebA_HQ"), "exp") == "exp/logs/celeba/celeba_hq.ckpt"
+    church = simple_checkpoint_path(cfg("LSUN", "church_outdoor"), "exp")
+    assert church == "exp/logs/diffusion_models_converted/ema_diffusion_lsun_church_model/model-4432000.ckpt"
+    assert simple_checkpoint_path(cfg("LSUN", "cat"), "exp").endswith("ema_diffusion_lsun_cat_model/model-1761000.ckpt")
+    assert simple_checkpoint_path(cfg("LSUN", "bedroom"), "exp").endswith("ema_diffusion_lsun_bedroom_model/model-2388000.ckpt")
+    with pytest.raises(ValueError):
+        simple_checkpoint_path(cfg("CIFAR10"), "exp")
+
+
+def test_every_reference_config_has_a_counterpart():
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["bedroom.yml", "cat.yml", "celeba_hq.yml", "church.yml", "imagenet_256.yml", "imagenet_256_cc.yml", "oldphoto.yml"]
+    for n in names:
+        cfg = yaml.safe_load(open(os.path.join(root, "configs", n)))
+        assert {"model", "diffusion", "data", "sampling", "time_travel"} <= set(cfg), n
+    ref_dir = "/root/reference/configs"
+    if os.path.isdir(ref_dir):
+        assert sorted(os.listdir(ref_dir)) == names
+        for n in names:
+            assert yaml.safe_load(open(os.path.join(root, "configs", n))) == yaml.safe_load(open(os.path.join(ref_dir, n))), n
+
+
+def test_respaced_betas_keep_only_integer_timesteps():
+    """hq_demo respace.py:96-101 keeps `i in use_timesteps` for integer i: fractional members (np.linspace oversampling)
+    are dropped, never truncated into duplicates (beta = 0)."""
+    import numpy as np
+    from ddnm_amd.hq_demo.respace import respaced_betas
+    betas = np.linspace(1e-4, 0.02, 1000)
+    new, keep = respaced_betas(betas, {0.0, 10.0, 10.5, 10.9, 20.0, 999.0})
+    assert keep == [0, 10, 20, 999] and np.all(new > 0)

@@ -159,8 +159,6 @@ def test_engine_hq_demo_vs_reference_golden(hip, golden, name, tmp_path, monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="added after the round's GPU budget was spent: not yet run on an MI355X "
-                                        "(the oracle side is pinned by test_oracle_hq_demo_golden); remove when green")
 @pytest.mark.parametrize("name", list(hq_cases.FACE_CASES))
 def test_engine_hq_demo_face_degradations(hip, golden, name, tmp_path, monkeypatch):
     """face256-only degradations of hq_demo (inpainting, mask_color_sr) with the loader's keep-mask."""

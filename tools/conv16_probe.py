@@ -14,7 +14,10 @@ from ddnm_amd._lib import Conv16Desc  # noqa: E402
 
 CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_build")
-VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16_NO_MAIN"]}
+VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16_NO_MAIN"],
+            "ne_nowl": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_WLOAD"], "ne_nosync": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_SYNC"],
+            "ne_nofrag": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG"],
+            "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"]}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 for i, a in enumerate(extra):
     VARIANTS[f"x{i}"] = a.split(",")
@@ -54,6 +57,9 @@ for name, Cin, Cout, H, k, res in [("warm", 256, 256, 256, 3, 1), ("64->256@256 
     d.src, d.weight, d.bias, d.out, d.stats_out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), stats.data_ptr()
     d.res = r.data_ptr() if res else None
     d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, H, Cin, Cout, k
+    if os.environ.get("GN") == "1" and k == 3:
+        gsc, gsh = torch.randn(B, Cin, device=dev), torch.randn(B, Cin, device=dev)
+        d.gn_scale, d.gn_shift, d.gn_silu = gsc.data_ptr(), gsh.data_ptr(), 1
     row = []
     for n, lib in libs.items():
         for _ in range(2):

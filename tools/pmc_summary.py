@@ -3,9 +3,13 @@
 for the dominant kernel.  FETCH_SIZE is doubled (gfx950 reports 1/2 of wide coalesced reads,
 MI355X_MICROARCH.md section HBM); both sizes are in KiB."""
 import json
+import os
+import sqlite3
 import sys
 
 import pandas as pd
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNEL = "conv3x3_halo_f32_kernel<2, 2, 2, 2>"
 
@@ -17,15 +21,32 @@ def pivot(path):
                           aggfunc="sum").reset_index()
 
 
-def main(root, out_json, out_md):
+def rocprof_avg_us(db, kernel):
+    """Average duration of `kernel` in a rocprofv3 --kernel-trace --stats database (the number bench.py's
+    event-based figure must agree with)."""
+    if not db or not os.path.exists(db):
+        return None
+    cur = sqlite3.connect(db).cursor()
+    for name, avg in cur.execute("select name, average from top_kernels"):
+        if kernel in name:
+            return float(avg)          # top_kernels durations are in us (tools/prof_summary.py)
+    return None
+
+
+def main(root, out_json, out_md, stats_db=None):
     m, f, w = (pivot(f"{root}/pmc_{k}/p_counter_collection.csv") for k in ("mfma", "fetch", "write"))
     n = len(m)
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs issue MFMA
     util = (m.SQ_VALU_MFMA_BUSY_CYCLES / (1024.0 * m.GRBM_GUI_ACTIVE / 8.0))
     fetch_b = f.FETCH_SIZE * 1024.0 * 2.0
     write_b = w.WRITE_SIZE * 1024.0
+    from ddnm_amd import build
     res = {
         "kernel": KERNEL, "launches_per_forward": n // 2, "passes": "2 forwards at B=8 per PMC pass",
+        # digest of the sources the profiled binary was built from: bench.py reports these figures only for a loaded
+        # library with the same digest (VERDICT r1: the r01 file went stale the moment a kernel changed)
+        "source_digest": build._digest(),
+        "rocprof_avg_launch_us": rocprof_avg_us(stats_db, KERNEL),
         "mfma_busy_frac_mean": float(util.mean()), "mfma_busy_frac_weighted": float(
             m.SQ_VALU_MFMA_BUSY_CYCLES.sum() / (1024.0 * m.GRBM_GUI_ACTIVE.sum() / 8.0)),
         "hbm_fetch_bytes_per_launch": float(fetch_b.mean()), "hbm_write_bytes_per_launch": float(write_b.mean()),
@@ -47,4 +68,4 @@ def main(root, out_json, out_md):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
