@@ -73,6 +73,8 @@ PROTOTYPES = {
     "ddnm_build_digest": (c_char_p, []),
     "ddnm_sizeof": (c_int32, [c_int32]),
     "ddnm_conv2d_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv3x3_small_cout_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv3x3_small_cout_f32_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_tile_n": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv2d_f32_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
@@ -138,6 +140,7 @@ PROTOTYPES = {
     "ddnm_avgpool2_nhwc_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                          c_int32, c_void_p]),
     "ddnm_embedding_add_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_nchw_im2col3x3_pad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_nchw_to_nhwc_pad_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_step_x0_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int64, POINTER(StepScalars),
                                    c_void_p]),
@@ -159,6 +162,9 @@ PROTOTYPES = {
     "ddnm_site_spectral_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
                                          c_int32, c_int32, c_void_p, c_int32, c_float, c_float, c_float, c_float,
                                          c_void_p]),
+    "ddnm_gather_scale_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int64, c_void_p]),
+    "ddnm_site_matmul_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64,
+                                       c_int32, c_void_p]),
     "ddnm_mul_planes_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

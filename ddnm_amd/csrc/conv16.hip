@@ -33,6 +33,9 @@ struct Conv16Args {
     int Hs, Ws;                                // source resolution (H/2 when ups)
 };
 
+#ifndef DDNM_P16_ILV
+#define DDNM_P16_ILV 1              // build-time probe switch (tools/conv16_probe.py): 0 = read burst before the MFMAs
+#endif
 constexpr int C16_KC = 64;          // channels per chunk (= 128 bytes per LDS row)
 constexpr int C16_BN = 256;
 constexpr int C16_ROWB = 128;       // LDS row pitch in bytes
@@ -237,12 +240,23 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) b[nxt][i] = *reinterpret_cast<const half8*>(lds + (pb[i] ^ ((ks + 1) << 5)));
             }
-            __builtin_amdgcn_sched_barrier(0);          // reads of step ks+1 issue first, then the 8 MFMAs of ks cover them
+            // 9-tap kernels: one LDS read of the next k-step behind each of the first MFMAs (-4 % vs a read burst up
+            // front); the 1-tap GEMM form measured better with the burst (its steps are dominated by the tile loads)
+            constexpr bool ILV = DDNM_P16_ILV && TAPS == 9 && MT * NT >= MT + NT;
+            if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][j], b[cur][i], acc[i][j], 0, 0, 0);
+            if (ILV && ks + 1 < 4) {
+#pragma unroll
+                for (int n = 0; n < MT + NT; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if constexpr (MT * NT > MT + NT) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -253,6 +267,9 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     const int SC = d.SC0 + d.SC1, nsk = d.skip0 ? SC / C16_KC : 0;
     const int s_begin = (int)((long)nsk * slice / p.ksplit), s_end = (int)((long)nsk * (slice + 1) / p.ksplit);
     const int n_main = c_end - c_begin, n_skip = s_end - s_begin;
+#ifdef DDNM_P16_PRIO_HALF        // probe: static priority for the later-dispatched half of the waves (MI355X_MICROARCH.md)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int hb = 0, wb = 0;
 #ifdef DDNM_P16_NO_MAIN
     if (false) {
@@ -489,10 +506,10 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const Conv16Args p, int tpi) {
     __shared__ f32x4 red[2][256];
     const ddnm_conv16_desc& d = p.d;
-    const int cb = blockIdx.y * 1024;
-    const int cw = min(1024, d.Cout - cb);
+    const int cb = blockIdx.y * 256;                  // 256 channels per workgroup: 64 float4 columns x 4 pixel rows
+    const int cw = min(256, d.Cout - cb);
     const int c4n = cw >> 2;
-    const int rows = 256 / c4n > 0 ? 256 / c4n : 1, active = rows * c4n;
+    const int rows = 256 / c4n, active = rows * c4n;
     const int hw = d.H * d.W, P = hw / tpi;
     const int b = blockIdx.x / tpi, t = blockIdx.x - b * tpi;
     const size_t slab = (size_t)p.M * d.Cout;
@@ -507,7 +524,9 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const 
         for (int pp = prow; pp < P; pp += rows) {
             const int p2 = t * P + pp;
             const size_t o = ((size_t)b * hw + p2) * d.Cout + n;
+            // all slices' loads are independent: issue them back to back (the slab sum is the latency chain here)
             f32x4 v = *reinterpret_cast<const f32x4*>(d.workspace + o);
+#pragma unroll 4
             for (int k = 1; k < p.ksplit; ++k) v = v + *reinterpret_cast<const f32x4*>(d.workspace + o + k * slab);
             v = v + add;
             if (res) {
@@ -543,9 +562,14 @@ struct Plan16 {
     int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
 };
 
+// pixel tiles per image of the split-K reduction: enough (image, tile, 256-channel slab) workgroups to cover the chip
+// twice, at least 4 pixels per tile
 static int splitk_tiles16(const ddnm_conv16_desc* d) {
     const int hw = d->H * d->W;
-    int tpi = hw / 4 < 64 ? hw / 4 : 64;
+    const int cy = (d->Cout + 255) / 256;
+    int tpi = 512 / (d->B * cy);
+    if (tpi > hw / 4) tpi = hw / 4;
+    if (tpi > 64) tpi = 64;
     if (tpi < 1) tpi = 1;
     while (tpi > 1 && hw % tpi) --tpi;
     return tpi;
@@ -606,10 +630,11 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     const int nchunks = d->Cin / C16_KC;
     int ks = 1;
     if (tiles < 160) {
-        ks = (int)((320 + tiles - 1) / tiles);
-        const int steps = nchunks;                 // keep >= 2 chunks per slice
-        if (ks > steps / 2) ks = steps / 2 > 0 ? steps / 2 : 1;
+        // ONE round of workgroups: tiles x slices <= 256 CUs (a 320-workgroup plan ran two rounds: 2x the time)
+        ks = (int)(256 / tiles);
+        if (ks > nchunks / 2) ks = nchunks / 2 > 0 ? nchunks / 2 : 1;      // keep >= 2 chunks per slice
         if (ks > 32) ks = 32;
+        if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;
     if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
@@ -674,7 +699,7 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     }
     if (pl.ksplit > 1) {
         const int tpi = pl.stats_tiles;
-        DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 1023) / 1024), dim3(256), 0, s, p, tpi);
+        DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 255) / 256), dim3(256), 0, s, p, tpi);
     }
     return 0;
 }

@@ -1,0 +1,91 @@
+// Output convolution of the celeba_hq `Model` (guided_diffusion/models.py:295-299,338-341): 3x3 / pad 1, 128 -> 3
+// channels, GroupNorm + swish fused in front, fp32 NCHW result.  HBM-bound (the input is read once: 268 MB at B = 8;
+// 3.6 GFLOP), so it runs on the vector ALU: on the MFMA tile kernel the 3 output channels are padded to a 32-wide N
+// tile and the launch is bound by 10.7x wasted matrix work (317 us measured; this kernel: the HBM read).
+//
+//   workgroup = 256 threads = an 8 x 32 pixel patch, one output pixel per thread, Cout <= 4 accumulators each;
+//   per 32-channel chunk the (8+2) x (32+2) halo goes through LDS with the GroupNorm affine + swish applied on the
+//   way (zero padding AFTER the activation, like the reference); its 9 x Cout x 32 weights sit next to it and are
+//   read as wave-wide broadcasts; the 9 taps read the halo at shifted rows (pitch 36 floats: conflict-free float4).
+#include "conv_common.h"
+
+constexpr int CS_TH = 8, CS_TW = 32, CS_KC = 32, CS_PITCH = 36, CS_MAXCO = 4;
+constexpr int CS_NP = (CS_TH + 2) * (CS_TW + 2);
+
+__global__ __launch_bounds__(256) void conv3x3_small_cout_f32_kernel(const ddnm_conv_desc d, int tiles_x, int tiles_per_img) {
+    __shared__ __attribute__((aligned(16))) float Hs[CS_NP * CS_PITCH];
+    __shared__ __attribute__((aligned(16))) float Ws[9 * CS_MAXCO * CS_KC];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x / tiles_per_img, t = blockIdx.x - img * tiles_per_img;
+    const int ty0 = (t / tiles_x) * CS_TH, tx0 = (t % tiles_x) * CS_TW;
+    const int Cin = d.C0, H = d.Hin, W = d.Win;
+    const int py = tid >> 5, px = tid & 31;
+    float acc[CS_MAXCO] = {0.f, 0.f, 0.f, 0.f};
+    for (int cb = 0; cb < Cin; cb += CS_KC) {
+        __syncthreads();                                   // previous chunk's reads are done
+        // halo: 340 pixels x 8 float4; thread -> (float4 column c4, pixels prow + 32*i)
+        const int c4 = tid & 7, prow = tid >> 3;
+        f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
+        if (d.gn_scale) {
+            gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * Cin + cb + c4 * 4);
+            gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * Cin + cb + c4 * 4);
+        }
+        for (int r = prow; r < CS_NP; r += 32) {
+            const int hy = r / (CS_TW + 2), hx = r - hy * (CS_TW + 2);
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                v = *reinterpret_cast<const f32x4*>(d.src0 + ((size_t)(img * H + iy) * W + ix) * Cin + cb + c4 * 4);
+                if (d.gn_scale) v = gn_act(v, gsc, gsh, d.gn_silu);
+            }
+            *reinterpret_cast<f32x4*>(&Hs[r * CS_PITCH + c4 * 4]) = v;
+        }
+        // weights of this chunk: Ws[(tap*Cout + o)*32 + c] = W[o][tap][cb + c]
+        for (int i = tid; i < 9 * d.Cout * CS_KC; i += 256) {
+            const int c = i & (CS_KC - 1), to = i >> 5;
+            const int tap = to / d.Cout, o = to - tap * d.Cout;
+            Ws[i] = d.weight[((size_t)o * 9 + tap) * Cin + cb + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* hp = &Hs[((py + tap / 3) * (CS_TW + 2) + px + tap % 3) * CS_PITCH];
+            const float* wp = &Ws[tap * d.Cout * CS_KC];
+#pragma unroll
+            for (int k4 = 0; k4 < CS_KC / 4; ++k4) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(hp + k4 * 4);
+#pragma unroll
+                for (int o = 0; o < CS_MAXCO; ++o) {
+                    if (o < d.Cout) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + o * CS_KC + k4 * 4);    // wave-wide broadcast
+                        acc[o] = fmaf(a.x, w.x, acc[o]);
+                        acc[o] = fmaf(a.y, w.y, acc[o]);
+                        acc[o] = fmaf(a.z, w.z, acc[o]);
+                        acc[o] = fmaf(a.w, w.w, acc[o]);
+                    }
+                }
+            }
+        }
+    }
+    const int oy = ty0 + py, ox = tx0 + px;
+#pragma unroll
+    for (int o = 0; o < CS_MAXCO; ++o)
+        if (o < d.Cout) d.out[(((size_t)img * d.Cout + o) * H + oy) * W + ox] = acc[o] + (d.bias ? d.bias[o] : 0.f);
+}
+
+static bool small_cout_ok(const ddnm_conv_desc* d) {
+    return d->ksize == 3 && d->stride == 1 && d->pad == 1 && d->Ho == d->Hin && d->Wo == d->Win && d->Cout >= 1 &&
+           d->Cout <= CS_MAXCO && d->out_nchw && d->C1 == 0 && !d->src1 && d->C0 % CS_KC == 0 && !d->ups && !d->res &&
+           !d->badd && !d->skip0 && !d->stats_out && d->Win % CS_TW == 0 && d->Hin % CS_TH == 0;
+}
+
+extern "C" int ddnm_conv3x3_small_cout_f32_supported(const ddnm_conv_desc* d) { return d && small_cout_ok(d) ? 1 : 0; }
+
+extern "C" int ddnm_conv3x3_small_cout_f32(const ddnm_conv_desc* d, void* stream) {
+    if (!d || !d->src0 || !d->weight || !d->out || d->B <= 0) return DDNM_E_BADARG;
+    if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
+    if (!small_cout_ok(d)) return DDNM_E_SHAPE;
+    const int tiles_x = d->Win / CS_TW, tpi = tiles_x * (d->Hin / CS_TH);
+    DDNM_LAUNCH(conv3x3_small_cout_f32_kernel, dim3(d->B * tpi), dim3(256), 0, (hipStream_t)stream, *d, tiles_x, tpi);
+    return 0;
+}

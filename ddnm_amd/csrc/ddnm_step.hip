@@ -537,6 +537,62 @@ extern "C" int ddnm_mul_planes_f32(const float* x, const float* table, int32_t p
     return 0;
 }
 
+// ---- generic pieces of the matrix-free SVD surface (A_functions.V / Vt / U / Ut / add_zeros / At / A_pinv_eta,
+// functions/svd_operators.py:9-97): a row gather with optional per-entry scale, and a small per-site matrix product.
+// out[b][i] = (idx[i] >= 0 ? in[b][idx[i]] : 0) * (scale ? scale[i] : 1);  idx NULL = identity for i < n_in, 0 beyond
+// (that is `add_zeros`, and with `scale` the `singulars * temp[:, :n]` products of A / At / A_pinv_eta).
+__global__ __launch_bounds__(256) void gather_scale_kernel(const float* __restrict__ in, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ scale, float* __restrict__ out,
+                                                           int64_t n_in, int64_t n_out, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t b = t / n_out, i = t - b * n_out;
+        const int64_t j = idx ? (int64_t)idx[i] : (i < n_in ? i : -1);
+        float v = j >= 0 ? in[b * n_in + j] : 0.f;
+        if (scale) v *= scale[i];
+        out[t] = v;
+    }
+}
+
+extern "C" int ddnm_gather_scale_f32(const float* in, const int32_t* idx, const float* scale, float* out, int32_t B,
+                                     int64_t n_in, int64_t n_out, void* stream) {
+    if (!in || !out || B <= 0 || n_in <= 0 || n_out <= 0) return DDNM_E_BADARG;
+    const int64_t total = (int64_t)B * n_out;
+    DDNM_LAUNCH(gather_scale_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, in, idx, scale, out, n_in, n_out,
+                total);
+    return 0;
+}
+
+// out[b][s][i] = sum_j Mop[i][j] in[b][s][j], Mop = M or M^T (n x n row-major, n <= 16), element (b, s, j) at
+// in[b*sb + s*ss + j*sj] (same strides for out): r x r patches in site-major order (ss = n, sj = 1) or RGB needles of
+// CHW planes (ss = 1, sj = H*W) -- the V_small / Vt_small products of svd_operators.py:490-517,636-656.
+__global__ __launch_bounds__(256) void site_matmul_kernel(const float* __restrict__ in, const float* __restrict__ M,
+                                                          float* __restrict__ out, int64_t sites_total, int64_t sites, int n,
+                                                          int64_t sb, int64_t ss, int64_t sj, int trans) {
+    __shared__ float Ms[16 * 16];
+    for (int i = threadIdx.x; i < n * n; i += 256) Ms[i] = M[i];
+    __syncthreads();
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < sites_total; t += (int64_t)gridDim.x * 256) {
+        const int64_t b = t / sites, sidx = t - b * sites;
+        const int64_t base = b * sb + sidx * ss;
+        float v[16];
+        for (int j = 0; j < n; ++j) v[j] = in[base + j * sj];
+        for (int i = 0; i < n; ++i) {
+            float a = 0.f;
+            for (int j = 0; j < n; ++j) a += (trans ? Ms[j * n + i] : Ms[i * n + j]) * v[j];
+            out[base + i * sj] = a;
+        }
+    }
+}
+
+extern "C" int ddnm_site_matmul_f32(const float* in, const float* M, float* out, int32_t B, int64_t sites, int32_t n,
+                                    int64_t sb, int64_t ss, int64_t sj, int32_t trans, void* stream) {
+    if (!in || !M || !out || B <= 0 || sites <= 0 || n <= 0 || n > 16 || in == out) return DDNM_E_BADARG;
+    const int64_t total = (int64_t)B * sites;
+    DDNM_LAUNCH(site_matmul_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, in, M, out, total, sites, n, sb, ss,
+                sj, trans);
+    return 0;
+}
+
 // DDNM+ spectral weights of Deblurring (svd_operators.py:1016-1091), evaluated per spectral entry from the
 // UNSORTED, un-thresholded singular table s[p] = s1_i * s1_j (the reference's sort :962 and its inverse cancel):
 //   mode 0 (Lambda :1016-1040):        out = x * lambda(s[p])

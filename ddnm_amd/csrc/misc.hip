@@ -80,6 +80,41 @@ extern "C" int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B
     return 0;
 }
 
+// im2col of the network's 3-channel input for the 3x3 / pad 1 input convolution (models.py:225, unet.py:472-476):
+// NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad] with entry k = (ky*3 + kx)*C + c = x[b][c][y+ky-1][x+kx-1] (0 outside,
+// 0 for k >= 9*C).  With C = 3 the 27 taps fit ONE 32-channel K chunk, so conv_in runs as a 1x1 convolution with
+// K = 32 instead of 9 taps x 32 zero-padded channels (K = 288, 10.7x the MFMA work: 350 us -> HBM-bound).
+__global__ __launch_bounds__(256) void nchw_im2col3x3_pad_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                 int C, int H, int W, int Cpad, size_t total4) {
+    const int q = Cpad >> 2, HW = H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int k4 = (int)(i % q);
+        const size_t pix = i / q;
+        const size_t b = pix / HW;
+        const int p = (int)(pix - b * HW);
+        const int y = p / W, x = p - y * W;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 * 4 + e;
+            const int tap = k / C, c = k - tap * C;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            v[e] = (tap < 9 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                       ? src[(b * C + c) * HW + (size_t)yy * W + xx] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(dst)[i] = f32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+extern "C" int ddnm_nchw_im2col3x3_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W,
+                                           int32_t Cpad, void* stream) {
+    if (!src || !dst || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cpad < 9 * C || (Cpad & 3)) return DDNM_E_BADARG;
+    const size_t total4 = (size_t)B * H * W * (Cpad / 4);
+    const unsigned grid = (unsigned)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    DDNM_LAUNCH(nchw_im2col3x3_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, H, W, Cpad, total4);
+    return 0;
+}
+
 // 2x2 average pooling of an NHWC tensor with an optional per-(sample, channel) affine + swish applied
 // to every input element first: out = mean_2x2(act(in)).  Replaces the `down=True` ResBlock halves
 // h = AvgPool2d(SiLU(GroupNorm(x))) and x = AvgPool2d(x)  (guided_diffusion/unet.py:133-140,237-242).

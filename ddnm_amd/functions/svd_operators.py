@@ -95,6 +95,44 @@ def _row_svd(row, device):
     return float(S[0]), V.contiguous().to(device)
 
 
+def _row_svd_u(row):
+    """U_small[0, 0] (= +-1) of the same decomposition (U / Ut of SuperResolution and Colorization, :519-523,658-662)."""
+    U, _, _ = torch.svd(torch.tensor([row], dtype=torch.float32), some=False)
+    return float(U[0, 0])
+
+
+def _gather(vec, idx, n_out, scale=None):
+    """out[b][i] = vec[b][idx[i]] (idx -1 -> 0; idx None: identity, zero padded) * scale[i] -- ddnm_gather_scale_f32."""
+    v = _flat(vec)
+    B, n_in = v.shape
+    out = torch.empty(B, n_out, dtype=torch.float32, device=v.device)
+    check(_lib.lib().ddnm_gather_scale_f32(_p(v), _p(idx), _p(scale), _p(out), B, n_in, n_out, ops._stream()),
+          "ddnm_gather_scale_f32")
+    return out
+
+
+def _site_matmul(vec, M, sites, n, sb, ss, sj, trans):
+    v = _flat(vec)
+    out = torch.empty_like(v)
+    check(_lib.lib().ddnm_site_matmul_f32(_p(v), _p(M), _p(out), v.shape[0], sites, n, sb, ss, sj, int(trans),
+                                          ops._stream()), "ddnm_site_matmul_f32")
+    return out
+
+
+def _pad_scale(f, n):
+    """Per-entry factors over the big (V) dimension: `f` on the first len(f) entries (zeros beyond are never read as the
+    gather writes 0 there)."""
+    out = torch.ones(n, dtype=torch.float32, device=f.device)
+    out[: f.numel()] = f
+    return out.contiguous()
+
+
+def _inverse_perm(idx):
+    inv = torch.empty_like(idx)
+    inv[idx.long()] = torch.arange(idx.numel(), dtype=idx.dtype)
+    return inv
+
+
 class A_functions:
     """Abstract base, same surface as svd_operators.py:9-97 (matrix-free SVD operator)."""
 
@@ -109,6 +147,38 @@ class A_functions:
 
     def singulars(self):
         raise NotImplementedError()
+
+    # ---- the matrix-free SVD surface (svd_operators.py:16-50).  The sampling path never calls these -- A / A_pinv /
+    # Lambda* above are evaluated in their direct forms -- but a drop-in offers them: the BASELINE operators implement
+    # V / Vt / U / Ut / add_zeros with the reference's spectral orderings, and At / A_pinv_eta follow from them exactly
+    # as the reference base class derives them (:60-66,82-91).
+    def V(self, vec):
+        raise NotImplementedError()
+
+    def Vt(self, vec):
+        raise NotImplementedError()
+
+    def U(self, vec):
+        raise NotImplementedError()
+
+    def Ut(self, vec):
+        raise NotImplementedError()
+
+    def add_zeros(self, vec):
+        raise NotImplementedError()
+
+    def _spectral_dim(self):
+        return self.channels * self.img_dim ** 2
+
+    def At(self, vec):                                              # :60-66
+        s = self.singulars().float().contiguous()
+        temp = self.Ut(vec)
+        return self.V(_gather(temp, None, self._spectral_dim(), scale=_pad_scale(s, self._spectral_dim())))
+
+    def A_pinv_eta(self, vec, eta):                                 # :82-91
+        s = self.singulars().float()
+        temp = self.Ut(vec)
+        return self.V(_gather(temp, None, self._spectral_dim(), scale=_pad_scale(s / (s * s + eta), self._spectral_dim())))
 
     def Lambda(self, vec, a, sigma_y, sigma_t, eta):
         raise NotImplementedError()
@@ -138,6 +208,11 @@ class Denoising(A_functions):
 
     def singulars(self):
         return torch.ones(self.channels * self.img_dim ** 2, device=self.device)
+
+    def V(self, vec):                                                      # svd_operators.py:447-462: all identities
+        return _flat(vec).clone()
+
+    Vt = U = Ut = add_zeros = V
 
     def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:464-469
         if float(sigma_t) < float(a) * sigma_y:
@@ -186,6 +261,45 @@ class SuperResolution(A_functions):
         if not hasattr(self, "_V"):
             self._s, self._V = _row_svd([1 / self.ratio ** 2] * self.ratio ** 2, self.device)
         return self._s, self._V
+
+    def _tables(self):
+        """Index tables of V / Vt (svd_operators.py:490-517): image (CHW) <-> site-major patches [C*y*y][r*r]
+        (`unfold(2,r,r).unfold(3,r,r)`) <-> spectral order (component 0 of every site first, then the other r*r-1
+        components interleaved per site: `recon[:, (S+idx)::(n-1)]`)."""
+        if not hasattr(self, "_t_img2site"):
+            C, d, r, yd = self.channels, self.img_dim, self.ratio, self.y_dim
+            n, S = r * r, C * yd * yd
+            c, py, px, dy, dx = torch.meshgrid(torch.arange(C), torch.arange(yd), torch.arange(yd), torch.arange(r),
+                                               torch.arange(r), indexing="ij")
+            img2site = (c * d * d + (py * r + dy) * d + (px * r + dx)).reshape(-1).to(torch.int32)     # [(s, j)] -> image index
+            sidx, k = torch.meshgrid(torch.arange(S), torch.arange(n), indexing="ij")
+            site2spec = torch.where(k == 0, sidx, S + sidx * (n - 1) + (k - 1)).reshape(-1).to(torch.int32)
+            dev = self.device
+            self._t_img2site, self._t_site2img = img2site.to(dev), _inverse_perm(img2site).to(dev)
+            self._t_site2spec, self._t_spec2site = site2spec.to(dev), _inverse_perm(site2spec).to(dev)
+        return self._t_img2site, self._t_site2img, self._t_site2spec, self._t_spec2site
+
+    def Vt(self, vec):                                                     # svd_operators.py:505-517
+        img2site, _, _, spec2site = self._tables()
+        n, N = self.ratio ** 2, self._spectral_dim()
+        t = _gather(vec, img2site, N)
+        t = _site_matmul(t, self._svd()[1], N // n, n, N, n, 1, trans=True)
+        return _gather(t, spec2site, N)
+
+    def V(self, vec):                                                      # :490-503
+        _, site2img, site2spec, _ = self._tables()
+        n, N = self.ratio ** 2, self._spectral_dim()
+        t = _gather(vec, site2spec, N)
+        t = _site_matmul(t, self._svd()[1], N // n, n, N, n, 1, trans=False)
+        return _gather(t, site2img, N)
+
+    def U(self, vec):                                                      # :519-523 (U is 1 x 1)
+        return _axpby(_flat(vec), None, _row_svd_u([1 / self.ratio ** 2] * self.ratio ** 2), 0.0)
+
+    Ut = U
+
+    def add_zeros(self, vec):                                              # :528-533
+        return _gather(vec, None, self._spectral_dim())
 
     def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:535-571
         s, V = self._svd()
@@ -242,6 +356,25 @@ class Colorization(A_functions):
             row = [0.3333, 0.3334, 0.3333] if self._w is None else [float(v) for v in self._w]
             self._s, self._V = _row_svd(row, self.device)
         return self._s, self._V
+
+    def _row(self):
+        return [0.3333, 0.3334, 0.3333] if self._w is None else [float(v) for v in self._w]
+
+    def Vt(self, vec):                                                     # svd_operators.py:647-656
+        hw = self.img_dim ** 2                  # needles of the CHW planes; the spectral order is component-major too
+        return _site_matmul(vec, self._svd()[1], hw, 3, 3 * hw, 1, hw, trans=True)
+
+    def V(self, vec):                                                      # :636-645
+        hw = self.img_dim ** 2
+        return _site_matmul(vec, self._svd()[1], hw, 3, 3 * hw, 1, hw, trans=False)
+
+    def U(self, vec):                                                      # :658-662
+        return _axpby(_flat(vec), None, _row_svd_u(self._row()), 0.0)
+
+    Ut = U
+
+    def add_zeros(self, vec):                                              # :667-671
+        return _gather(vec, None, self._spectral_dim())
 
     def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:669-695
         s, V = self._svd()
@@ -304,6 +437,33 @@ class Inpainting(A_functions):
 
     def singulars(self):
         return torch.ones(3 * self.n_kept, device=self.device)
+
+    def _tables(self):
+        """Vt = the permutation [kept (ascending HWC-interleaved index), missing (in `missing_indices` order)] of the
+        HWC-interleaved image (svd_operators.py:339-344); V its inverse."""
+        if not hasattr(self, "_t_vt"):
+            hw = self.img_dim ** 2
+            miss = self.missing_indices.detach().cpu().long()
+            keep = torch.ones(3 * hw, dtype=torch.bool)
+            keep[miss] = False
+            order = torch.cat([torch.nonzero(keep).reshape(-1), miss])          # spectral position -> HWC index
+            img = ((order % 3) * hw + order // 3).to(torch.int32)               # HWC index p*3 + c -> CHW index c*HW + p
+            self._t_vt, self._t_v = img.to(self.device), _inverse_perm(img).to(self.device)
+        return self._t_vt, self._t_v
+
+    def Vt(self, vec):
+        return _gather(vec, self._tables()[0], self._spectral_dim())
+
+    def V(self, vec):                                                      # :332-337
+        return _gather(vec, self._tables()[1], self._spectral_dim())
+
+    def U(self, vec):                                                      # :346-350
+        return _flat(vec).clone()
+
+    Ut = U
+
+    def add_zeros(self, vec):                                              # :355-359
+        return _gather(vec, None, self._spectral_dim())
 
     def Lambda(self, vec, a, sigma_y, sigma_t, eta):                       # svd_operators.py:361-387
         lam = spectral_coefficients(1.0, a, sigma_y, sigma_t, eta)[0]
@@ -369,6 +529,31 @@ class WalshHadamardCS(A_functions):
 
     def singulars(self):
         return torch.ones(self.n_keep, device=self.device)
+
+    def Vt(self, vec):                                                     # svd_operators.py:236-237: fwht, permute, (k, c) interleave
+        x = _img(vec, self.channels, self.img_dim)
+        B = x.shape[0]
+        coef = self._fwht(x)
+        z = torch.empty(B, self.channels * self.N, dtype=torch.float32, device=x.device)
+        check(_lib.lib().ddnm_wh_gather_f32(_p(coef), _p(self.perm), _p(z), B, self.channels, self.N,
+                                            self.channels * self.N, ops._stream()), "ddnm_wh_gather_f32")
+        return z
+
+    def V(self, vec):                                                      # :231-234
+        z = _flat(vec)
+        B = z.shape[0]
+        planes = torch.empty(B, self.channels, self.N, dtype=torch.float32, device=z.device)
+        check(_lib.lib().ddnm_wh_scatter_f32(_p(z), _p(self.perm), _p(planes), B, self.channels, self.N,
+                                             self.channels * self.N, ops._stream()), "ddnm_wh_scatter_f32")
+        return self._fwht(planes).reshape(B, -1)
+
+    def U(self, vec):                                                      # :239-243
+        return _flat(vec).clone()
+
+    Ut = U
+
+    def add_zeros(self, vec):                                              # :248-251
+        return _gather(vec, None, self._spectral_dim())
 
     def _fwht(self, planes):
         out = torch.empty_like(planes)
@@ -502,6 +687,16 @@ def mask_color_sr(channels, img_dim, mask, scale, device):
                         SuperResolution(1, img_dim, int(scale), device)])
 
 
+class GeneralA(A_functions):
+    """svd_operators.py:173-208: an explicit dense A with a full LAPACK SVD, used by none of the `--deg` choices of
+    guided_diffusion/diffusion.py:451-523.  Not rebuilt: a dense d x d operator at 3 x 256 x 256 is 1.5 TB."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("GeneralA (functions/svd_operators.py:173-208, dense matrix + torch.svd) is not part of "
+                                  "the DDNM sampling path; wrap the matrix in an object with A / A_pinv and pass it to "
+                                  "ddnm_diffusion as a foreign operator")
+
+
 class SRConv(A_functions):
     ZERO = 3e-2     # svd_operators.py:878
 
@@ -527,6 +722,62 @@ class SRConv(A_functions):
         self.singulars_small = S.to(device)
         self.Ae = ((U * S[None, :]) @ V[:, :small].T).contiguous().to(device)       # [small, img_dim]
         self.Pe = ((V[:, :small] * Sp[None, :]) @ U.T).contiguous().to(device)      # [img_dim, small]
+        self._svd_host = (U.contiguous(), V.contiguous())     # factors of the spectral surface (V / Vt / U / Ut), built lazily
+
+    # ---- matrix-free SVD surface (svd_operators.py:886-931); the sampling path uses the Ae / Pe forms above
+    def _spectral(self):
+        if not hasattr(self, "_Vs"):
+            U, V = self._svd_host
+            dev, d, m, C = self.device, self.img_dim, self.small_dim, self.channels
+            self._Vs, self._Vts = V.to(dev), V.T.contiguous().to(dev)
+            self._Us, self._Uts = U.to(dev), U.T.contiguous().to(dev)
+            # P_1 of Appendix D.5 (:881-884): the small x small block first, then the rest of the first `small` rows
+            perm = torch.tensor([d * i + j for i in range(m) for j in range(m)] +
+                                [d * i + j for i in range(m) for j in range(m, d)], dtype=torch.long)
+            src = torch.arange(d * d)
+            src[: perm.numel()] = perm                                   # spectral position -> row-major (i, j) entry
+            pos, c = torch.meshgrid(torch.arange(d * d), torch.arange(C), indexing="ij")
+            vt = (c * d * d + src[pos]).reshape(-1).to(torch.int32)      # [(pos, c)] -> CHW index of V^T X V
+            self._t_vt, self._t_v = vt.to(dev), _inverse_perm(vt).to(dev)
+            pos, c = torch.meshgrid(torch.arange(m * m), torch.arange(C), indexing="ij")
+            ut = (c * m * m + pos).reshape(-1).to(torch.int32)           # [(pos, c)] -> CHW index of the small image
+            self._t_ut, self._t_u = ut.to(dev), _inverse_perm(ut).to(dev)
+        return self
+
+    def _sandwich(self, L, x, Rt, rows, cols, inner):
+        """L X R for every (b, c) plane: L [rows x inner], X [inner x inner], R given transposed as Rt [cols x inner]."""
+        bc = x.numel() // (inner * inner)
+        t1 = torch.empty(bc, rows, inner, dtype=torch.float32, device=x.device)
+        ops.bgemm(L, x, t1, rows, inner, inner, lda=inner, ldb=inner, ldc=inner, transb=False, batch=bc,
+                  sB=(inner * inner, 0), sC=(rows * inner, 0))
+        out = torch.empty(bc, rows, cols, dtype=torch.float32, device=x.device)
+        ops.bgemm(t1, Rt, out, rows, cols, inner, lda=inner, ldb=inner, ldc=cols, transb=True, batch=bc,
+                  sA=(rows * inner, 0), sC=(rows * cols, 0))
+        return out
+
+    def Vt(self, vec):                                                     # :899-907: V^T X V, then P_1 and (pos, c) interleave
+        sp, d = self._spectral(), self.img_dim
+        t = self._sandwich(sp._Vts, _img(vec, self.channels, d), sp._Vts, d, d, d)
+        return _gather(t.reshape(vec.shape[0], -1), sp._t_vt, self._spectral_dim())
+
+    def V(self, vec):                                                      # :886-897
+        sp, d = self._spectral(), self.img_dim
+        t = _gather(vec, sp._t_v, self._spectral_dim())
+        return self._sandwich(sp._Vs, t, sp._Vs, d, d, d).reshape(vec.shape[0], -1)
+
+    def Ut(self, vec):                                                     # :919-925
+        sp, m = self._spectral(), self.small_dim
+        y = _flat(vec)
+        t = self._sandwich(sp._Uts, y, sp._Uts, m, m, m)
+        return _gather(t.reshape(y.shape[0], -1), sp._t_ut, self.channels * m * m)
+
+    def U(self, vec):                                                      # :909-917
+        sp, m = self._spectral(), self.small_dim
+        t = _gather(vec, sp._t_u, self.channels * m * m)
+        return self._sandwich(sp._Us, t, sp._Us, m, m, m).reshape(vec.shape[0], -1)
+
+    def add_zeros(self, vec):                                              # :930-934
+        return _gather(vec, None, self._spectral_dim())
 
     def _A(self, x, y_sub=None):
         """Y = Ae X Ae^T (- y_sub) for every (b, c) plane."""

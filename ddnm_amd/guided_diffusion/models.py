@@ -59,6 +59,7 @@ class Model:
         self.device = torch.device("cuda") if device is None else torch.device(device)
         self._plan()
         self.w = None
+        self._ws, self._ws_by_stream, self._graphs = None, {}, None
 
     # ------------------------------------------------------------------ structure
     def _plan(self):
@@ -197,6 +198,8 @@ class Model:
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
         w["conv_in.weight"] = ops.pack_conv_weight(g("conv_in.weight"), cin_pad=CIN_PAD)
         w["conv_in.bias"] = g("conv_in.bias")
+        if 9 * self.in_channels <= CIN_PAD:       # 3 input channels: the 27 taps fit one 32-wide K chunk
+            w["conv_in.weight.im2col"] = ops.pack_conv_in_weight_im2col(g("conv_in.weight"), CIN_PAD)
         tw, tb = [], []
         for rb in self.res_blocks:
             n = rb.name
@@ -242,11 +245,17 @@ class Model:
         w["temb.freq"] = freq.to(dev)
         self.w = w
         self._ws = None
+        self._ws_by_stream = {}
+        if getattr(self, "_graphs", None) is not None:
+            self._graphs.reset()
         return self
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B):
-        if self._ws is None or self._ws_B < B:
+        """GroupNorm scratch of the current stream (one per stream: see ddnm_amd/graph.py)."""
+        key = torch.cuda.current_stream().cuda_stream
+        ent = self._ws_by_stream.get(key)
+        if ent is None or ent[1] < B:
             r = self.resolution
             max_partial = 0
             # bound over the (HW, C) pairs that occur: C <= max_ch at every resolution
@@ -255,8 +264,9 @@ class Model:
                 for c in (self.ch, self.max_ch):
                     max_partial = max(max_partial, ops.gn_nchunk(res * res, c))
                 res //= 2
-            self._ws = ops.GroupNormWorkspace(self.device, B, self.max_ch, B * max_partial * 32 * 2)
-            self._ws_B = B
+            ent = (ops.GroupNormWorkspace(self.device, B, self.max_ch, B * max_partial * 32 * 2), B)
+            self._ws_by_stream[key] = ent
+        self._ws = ent[0]
         return self._ws
 
     def _gn(self, x0, x1, name):
@@ -297,7 +307,22 @@ class Model:
                   sA=(T * T, 0), sB=(T * 3 * C, 0), sC=(T * C, 0))
         return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
 
+    def enable_graphs(self, two_streams=False):
+        """Replay the forward from a captured hipGraph (ddnm_amd/graph.py)."""
+        from ..graph import GraphedForward
+        self._graphs = GraphedForward(lambda x, t, y: self._forward_eager(x, t), two_streams=two_streams)
+        return self
+
+    def disable_graphs(self):
+        self._graphs = None
+        return self
+
     def forward(self, x, t):
+        if getattr(self, "_graphs", None) is not None:
+            return self._graphs(x, t, None)
+        return self._forward_eager(x, t)
+
+    def _forward_eager(self, x, t):
         if self.w is None:
             raise RuntimeError("load_state_dict() must be called before forward()")
         assert x.shape[2] == x.shape[3] == self.resolution
@@ -310,8 +335,13 @@ class Model:
         temb = ops.linear(temb, w["temb.dense.1.weight"], w["temb.dense.1.bias"], silu_in=True)
         tproj = ops.linear(temb, w["temb_proj_cat.weight"], w["temb_proj_cat.bias"], silu_in=True)
 
-        xin = ops.nchw_to_nhwc_pad(x.contiguous(), CIN_PAD)
-        hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"], emit_stats=True)]
+        if "conv_in.weight.im2col" in w:
+            # conv_in as a 1x1 convolution over the im2col'ed image: K = 32 instead of 9 x 32 zero-padded channels
+            xin = ops.nchw_im2col3x3_pad(x.contiguous(), CIN_PAD)
+            hs = [ops.conv2d(xin, w["conv_in.weight.im2col"], self.ch, 1, bias=w["conv_in.bias"], emit_stats=True)]
+        else:
+            xin = ops.nchw_to_nhwc_pad(x.contiguous(), CIN_PAD)
+            hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"], emit_stats=True)]
         for lvl, (blocks, attns, has_down, c) in enumerate(self.down):
             for ib, rb in enumerate(blocks):
                 h = self._resblock(rb, hs[-1], None, tproj)
@@ -342,4 +372,5 @@ class Model:
         return ops.conv2d(h, w["conv_out.weight"], self.out_ch, 3, gn=gn, gn_silu=True, bias=w["conv_out.bias"],
                           out_nchw=True)
 
-    __call__ = forward
+    def __call__(self, x, t):
+        return self.forward(x, t)

@@ -120,6 +120,8 @@ class UNetModel:
         self.max_ch = max(L[1] for _, L in self._res_names)
         self.w = None
         self._ws = None
+        self._ws_by_stream = {}
+        self._graphs = None
         self.use_fp16 = False
 
     def _walk(self):
@@ -286,6 +288,9 @@ class UNetModel:
         w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         self.w = w
         self._ws = None
+        self._ws_by_stream = {}
+        if self._graphs is not None:
+            self._graphs.reset()
         if self.use_fp16:
             self._pack_f16()
             self._pack_h16()
@@ -296,13 +301,18 @@ class UNetModel:
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B):
-        if self._ws is None or self._ws_B < B:
+        """GroupNorm scratch of the current stream (the affine of one GroupNorm is consumed by the next launch on the
+        same stream; the two half-batch streams of a captured forward each own one)."""
+        key = torch.cuda.current_stream().cuda_stream
+        ent = self._ws_by_stream.get(key)
+        if ent is None or ent[1] < B:
             res, mp = self.image_size, 0
             while res >= 8:
                 mp = max(mp, ops.gn_nchunk(res * res, min(self.max_ch, 4096)))
                 res //= 2
-            self._ws = ops.GroupNormWorkspace(self.device, B, self.max_ch, B * mp * 32 * 2)
-            self._ws_B = B
+            ent = (ops.GroupNormWorkspace(self.device, B, self.max_ch, B * mp * 32 * 2), B)
+            self._ws_by_stream[key] = ent
+        self._ws = ent[0]
         return self._ws
 
     def _gn(self, x0, x1, name, film=None):
@@ -475,11 +485,27 @@ class UNetModel:
         # images narrower than one 32-pixel output tile (reduced test nets): the exact-fp32 kernel on the fp16 operand
         return ops.conv2d(a.float(), w["out.2.weight"], self.out_channels, 3, bias=w["out.2.bias"], out_nchw=True)
 
+    def enable_graphs(self, two_streams=True):
+        """Replay the forward from a captured hipGraph (one per batch shape): no per-launch host work, and with
+        `two_streams` the two halves of the batch run as concurrent branches of the graph (ddnm_amd/graph.py)."""
+        from ..graph import GraphedForward
+        self._graphs = GraphedForward(self._forward_eager, two_streams=two_streams)
+        return self
+
+    def disable_graphs(self):
+        self._graphs = None
+        return self
+
     def forward(self, x, timesteps, y=None):
         if self.w is None:
             raise RuntimeError("load_state_dict() must be called before forward()")
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
+        if self._graphs is not None:
+            return self._graphs(x, timesteps, y)
+        return self._forward_eager(x, timesteps, y)
+
+    def _forward_eager(self, x, timesteps, y=None):
         w = self.w
         B = x.shape[0]
         self._workspace(B)
@@ -519,4 +545,5 @@ class UNetModel:
         return ops.conv2d(h, w["out.2.weight"], self.out_channels, 3, gn=gn, gn_silu=True, bias=w["out.2.bias"],
                           out_nchw=True)
 
-    __call__ = forward
+    def __call__(self, x, timesteps, y=None):
+        return self.forward(x, timesteps, y)

@@ -63,11 +63,13 @@ _conv_ws = {}
 
 
 def _conv_workspace(device, floats):
-    """Split-K scratch, one buffer per device, grown on demand (stream order makes reuse safe)."""
-    ws = _conv_ws.get(device)
+    """Split-K scratch, one buffer per (device, stream), grown on demand: stream order makes reuse safe within a
+    stream, and the two half-batch streams of a captured forward (ddnm_amd/graph.py) must not share one."""
+    key = (device, _stream())
+    ws = _conv_ws.get(key)
     if ws is None or ws.numel() < floats:
         ws = torch.empty(int(floats), dtype=torch.float32, device=device)
-        _conv_ws[device] = ws
+        _conv_ws[key] = ws
     return ws
 
 
@@ -129,10 +131,11 @@ _f16_scratch_buf = {}
 def _f16_scratch(device, numel, slot=0):
     """fp16 activation scratch of the GroupNorm pre-pass (slot 0) / the im2col matrix (slot 1); stream order makes
     reuse safe."""
-    buf = _f16_scratch_buf.get((device, slot))
+    key = (device, slot, _stream())
+    buf = _f16_scratch_buf.get(key)
     if buf is None or buf.numel() < numel:
         buf = torch.empty(numel, dtype=torch.float16, device=device)
-        _f16_scratch_buf[(device, slot)] = buf
+        _f16_scratch_buf[key] = buf
     return buf
 
 
@@ -166,6 +169,18 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
     d.badd_stride, d.tile, d.res_ups = badd_stride, tile, int(res_ups)
     L = _lib.lib()
+    if out_nchw and cout <= 4 and skip is None and weight_f16 is None and L.ddnm_conv3x3_small_cout_f32_supported(ctypes.byref(d)) == 1:
+        # the network's 3-channel output convolution: HBM-bound vector-ALU kernel (csrc/conv_small_f32.hip)
+        if _timer is None:
+            check(L.ddnm_conv3x3_small_cout_f32(ctypes.byref(d), _stream()), "ddnm_conv3x3_small_cout_f32")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(L.ddnm_conv3x3_small_cout_f32(ctypes.byref(d), _stream()), "ddnm_conv3x3_small_cout_f32")
+            e1.record()
+            _timer.records.append(("conv3x3_small_cout_f32", 2.0 * B * Ho * Wo * cout * 9 * C0, e0, e1))
+            _timer.shapes.append((B, Ho, Wo, C0, cout, 3, 1, 0, 0, gn is not None, False))
+        return Act(out, None, 0) if emit_stats else out
     # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
     # shape qualifies; everything else runs the exact-fp32 kernels
     f16, f16_1x1 = False, False
@@ -544,6 +559,26 @@ def nchw_to_nhwc_pad(x, cpad):
     check(_lib.lib().ddnm_nchw_to_nhwc_pad_f32(_p(_f32c(x, "x")), _p(out), B, C, H * W, cpad, _stream()),
           "ddnm_nchw_to_nhwc_pad_f32")
     return out
+
+
+def nchw_im2col3x3_pad(x, cpad):
+    """[B,C,H,W] -> NHWC [B,H,W,cpad] holding the 9*C taps of the 3x3 / pad 1 input convolution (C = 3: one K chunk)."""
+    B, C, H, W = x.shape
+    out = torch.empty(B, H, W, cpad, dtype=torch.float32, device=x.device)
+    check(_lib.lib().ddnm_nchw_im2col3x3_pad_f32(_p(_f32c(x, "x")), _p(out), B, C, H, W, cpad, _stream()),
+          "ddnm_nchw_im2col3x3_pad_f32")
+    return out
+
+
+def pack_conv_in_weight_im2col(w, cpad):
+    """conv_in weights [Cout, C, 3, 3] -> the 1x1 form over the im2col'ed input: [Cout_pad][1][cpad], entry
+    (ky*3+kx)*C + c (the order ddnm_nchw_im2col3x3_pad_f32 writes)."""
+    cout, cin = w.shape[0], w.shape[1]
+    flat = w.float().permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+    cout_pad = (cout + CONV_COUT_ALIGN - 1) // CONV_COUT_ALIGN * CONV_COUT_ALIGN
+    out = torch.zeros(cout_pad, 1, cpad, dtype=torch.float32, device=w.device)
+    out[:cout, 0, :9 * cin] = flat
+    return out.contiguous()
 
 
 # ----------------------------------------------------------------------------- sampler step

@@ -99,6 +99,13 @@ int ddnm_conv2d_f32_stats_tiles(const ddnm_conv_desc* d);
 /* 1 if this launch would run the 3x3 halo kernel and can therefore take the fused shortcut fields. */
 int ddnm_conv2d_f32_fuses_skip(const ddnm_conv_desc* d);
 
+/* Output convolution with <= 4 output channels (conv_out of the celeba `Model`, guided_diffusion/models.py:295-299): same
+ * descriptor with ksize 3, stride 1, pad 1, out_nchw = 1, one source, Cin % 32 == 0, Win % 32 == 0, Hin % 8 == 0, optional
+ * fused GroupNorm affine + swish and bias; no residual / shortcut / statistics.  HBM-bound vector-ALU kernel (on the
+ * MFMA tile kernel the 3 channels are padded to a 32-wide N tile: 10x the matrix work). */
+int ddnm_conv3x3_small_cout_f32(const ddnm_conv_desc* d, void* stream);
+int ddnm_conv3x3_small_cout_f32_supported(const ddnm_conv_desc* d);
+
 /* 3x3 / stride 1 / pad 1 convolution with fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate:
  * the reference's `use_fp16` torso (guided_diffusion/unet.py:619-625, fp16_util.py:15-22).  Same descriptor;
  * `weight` points to the (O,ky,kx,I)-packed weights stored as IEEE fp16, activations / bias / residual /
@@ -299,6 +306,11 @@ int ddnm_embedding_add_f32(float* emb, const float* table, const int64_t* idx, i
 /* NCHW [B][C][H][W] -> NHWC [B][H][W][Cpad], channels >= C zero filled. */
 int ddnm_nchw_to_nhwc_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t HW, int32_t Cpad,
                               void* stream);
+/* im2col of the 3-channel network input for the 3x3 / pad 1 input convolution (models.py:225, unet.py:472-476):
+ * dst[b][y][x][(ky*3+kx)*C + c] = src[b][c][y+ky-1][x+kx-1] (0 outside the image and for entries >= 9*C), so that
+ * conv_in is ONE 32-wide K chunk (a 1x1 convolution over 27 real entries) instead of 9 taps x 32 padded channels. */
+int ddnm_nchw_im2col3x3_pad_f32(const float* src, float* dst, int32_t B, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                                void* stream);
 
 /* ------------------------------------------------------------------------- *
  * DDNM sampler step (functions/svd_ddnm.py:57-65,74; guided_diffusion/diffusion.py:365-384).
@@ -354,6 +366,16 @@ int ddnm_axpby_strided_f32(const float* x, int64_t x_bstride, const float* y, fl
  * Lambda / Lambda_noise of Inpainting (svd_operators.py:361-439), spectral weights of WalshHadamardCS (:253-320). */
 int ddnm_mask_mix_f32(const float* x, const float* y, const float* mask, int32_t planes_mask, int64_t plane_elems,
                       float* out, int64_t total, float cx_m, float cx_n, float cy_m, float cy_n, void* stream);
+/* Matrix-free SVD surface of the operators (A_functions.V / Vt / U / Ut / add_zeros / At / A_pinv_eta,
+ * functions/svd_operators.py:9-97; not on the sampling hot path):
+ *   gather_scale: out[b][i] = (idx[i] >= 0 ? in[b][idx[i]] : 0) * (scale ? scale[i] : 1); idx NULL = identity padded with
+ *                 zeros up to n_out (`add_zeros`, and with `scale` the `singulars * temp[:, :n]` products);
+ *   site_matmul:  out[b][s][i] = sum_j Mop[i][j] in[b][s][j] with Mop = M (trans 0) or M^T, n <= 16, element (b,s,j) at
+ *                 b*sb + s*ss + j*sj in both tensors (the V_small / Vt_small products, :490-517,636-656); in != out. */
+int ddnm_gather_scale_f32(const float* in, const int32_t* idx, const float* scale, float* out, int32_t B, int64_t n_in,
+                          int64_t n_out, void* stream);
+int ddnm_site_matmul_f32(const float* in, const float* M, float* out, int32_t B, int64_t sites, int32_t n, int64_t sb,
+                         int64_t ss, int64_t sj, int32_t trans, void* stream);
 /* Per-site spectral ops with the n x n orthogonal V (device, row-major) of a 1 x n measurement row:
  * mode 0 = r x r patches of [B*C][H][W] planes (SuperResolution, :535-623), mode 1 = RGB needles (Colorization, :669-736);
  * op 0: out = x + (c0-1) V[:,0] (V[:,0].x)  (Lambda, c0 = lambda of the measured direction);

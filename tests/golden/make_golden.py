@@ -335,6 +335,34 @@ def make_adm():
     np.savez_compressed(os.path.join(HERE, "adm_forward.npz"), **out)
 
 
+def make_spectral():
+    """The matrix-free SVD surface of the five BASELINE operators at 64 x 64 through the REAL reference classes
+    (functions/svd_operators.py:9-97 and the per-class V / Vt / U / Ut / add_zeros): tests/golden/spectral.npz.
+    V / Vt of the permutation-type operators are unique; for the operators built on a LAPACK SVD only the
+    basis-independent products (At, A_pinv_eta, A) are compared tightly by the tests."""
+    ns = ref_import.load()
+    R = ns.svd_operators
+    out = {}
+    d = 64
+    x = cases.operator_input(d, 2)
+    g = torch.Generator().manual_seed(cases.SEED + 31)
+    SP = lambda t: t[:, ::5].contiguous()        # noqa: E731  (every 5th entry of the big vectors)
+    for name in ("sr_averagepooling", "sr_bicubic", "colorization", "inpainting", "cs_walshhadamard"):
+        op = ref_operator(R, name, d)
+        y = op.A(x)
+        z = torch.randn(2, 3 * d * d, generator=g)
+        w = torch.randn(*y.shape, generator=g)
+        out[f"{name}_Vt"] = SP(op.Vt(x.clone())).numpy()
+        out[f"{name}_V"] = SP(op.V(z.clone())).numpy()
+        out[f"{name}_Ut"] = op.Ut(w.clone()).numpy()
+        out[f"{name}_U"] = op.U(w.clone()).numpy()
+        out[f"{name}_add_zeros"] = op.add_zeros(w.clone())[:, ::7].numpy()
+        out[f"{name}_At"] = SP(op.At(w.clone())).numpy()
+        out[f"{name}_A_pinv_eta"] = SP(op.A_pinv_eta(w.clone(), 0.3)).numpy()
+        out[f"{name}_z"], out[f"{name}_w"] = z.numpy(), w.numpy()
+    np.savez_compressed(os.path.join(HERE, "spectral.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+
+
 def make_full(names):
     """--full-adm / --full-c2b8: the FULL BASELINE configurations through the real reference loop
     (functions/svd_ddnm.py:19-78), operators built as guided_diffusion/diffusion.py:451-523 builds them, fp32
@@ -414,9 +442,12 @@ def main():
     ap.add_argument("--cs-only", action="store_true", help="only (re)generate the block-based CS goldens")
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
+    ap.add_argument("--spectral-only", action="store_true", help="only (re)generate the V / Vt / U / Ut / At goldens")
     args = ap.parse_args()
     if args.full_cases:
         return make_full(args.full_cases.split(","))
+    if args.spectral_only:
+        return make_spectral()
     if args.classifier_only:
         return make_classifier()
     if args.plus_deblur_only:

@@ -240,3 +240,27 @@ def test_adm_sampler_fp16_torso_psnr_bar(hip, name, golden_dir):
     assert 1e-7 < err < 2e-2, err
     assert (sampler.psnr(got, x_orig) - sampler.psnr(ref, x_orig)).abs().max().item() <= 0.1
     assert sampler.psnr(got, ref).min().item() > 35.0
+
+
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_adm_graph_replay_matches_eager(hip, two_streams):
+    """The captured-graph forward (ddnm_amd/graph.py; optionally the two half-batches as concurrent branches) returns
+    what the eager forward returns, replay after replay, for changing inputs."""
+    from oracle import cases
+    cfg, sd = cases.adm_net("mid")
+    m = build(cfg, sd)
+    m.convert_to_fp16()
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(4, 3, 64, 64, generator=g).cuda() for _ in range(3)]
+    ts = [torch.tensor([990.0, 500.0, 20.0, 0.0]).cuda(), torch.full((4,), 430.0).cuda(), torch.full((4,), 10.0).cuda()]
+    eager = [m(x, t).clone() for x, t in zip(xs, ts)]
+    m.enable_graphs(two_streams=two_streams)
+    for rep in range(2):
+        for x, t, want in zip(xs, ts, eager):
+            got = m(x, t)
+            torch.cuda.synchronize()
+            if two_streams:        # half batches take other split-K plans: fp32 summation order, then fp16 roundings
+                assert rel(got, want) < 2e-3
+            else:
+                assert torch.equal(got, want)
+    m.disable_graphs()

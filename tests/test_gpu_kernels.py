@@ -320,3 +320,80 @@ def test_conv_fused_shortcut(hip, f16, B, C, C0, C1, H):
                      weight_f16=ops.pack_conv_weight_f16(w2.cuda()) if f16 else None)
     torch.cuda.synchronize()
     assert rel(nchw(out.cpu()), ref) < (2e-3 if f16 else 3e-6)
+
+
+@pytest.mark.parametrize("name", ["sr_averagepooling", "sr_bicubic", "colorization", "inpainting", "cs_walshhadamard",
+                                  "denoising"])
+def test_operator_svd_surface(hip, name, golden_dir):
+    """V / Vt / U / Ut / add_zeros / At / A_pinv_eta of the BASELINE operators (functions/svd_operators.py:9-97 and the
+    per-class definitions).  Algebra first (basis-independent): V Vt = I, U Ut = I, A = U S Vt[:n], At and A_pinv_eta as
+    the reference base class derives them; then the reference's own outputs (tests/golden/spectral.npz, every 5th
+    entry): exact orderings for the permutation-type operators, and the basis-independent products for the operators
+    built on a LAPACK SVD (their V_small columns are unique only up to sign / rotation of degenerate subspaces)."""
+    from tests.helpers import engine_operator
+    d, B = 64, 2
+    op = engine_operator(name, d)
+    from oracle import cases
+    x = cases.operator_input(d, B).cuda()
+    xf = x.reshape(B, -1)
+    assert rel(op.V(op.Vt(x)), xf) < 2e-6 and rel(op.Vt(op.V(xf)), xf) < 2e-6
+    y = op.A(x)
+    assert rel(op.U(op.Ut(y)), y) < 2e-6
+    s = op.singulars().float()
+    n = s.numel()
+    assert rel(op.U(s * op.Vt(x)[:, :n]), y) < 2e-5                       # A = U S V^T (:52-58)
+    z = op.add_zeros(y)
+    assert z.shape == (B, 3 * d * d) and torch.equal(z[:, :n], y) and not bool(z[:, n:].any())
+    # <A x, w> = <x, At w>
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(B, n, generator=g).cuda()
+    lhs = (y.double() * w.double()).sum()
+    rhs = (xf.double() * op.At(w).double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-4
+    # A_pinv_eta(., 0) restricted to the non-zero singular values is A_pinv
+    if float(s.min()) > 0:
+        assert rel(op.A_pinv_eta(w, 0.0), op.A_pinv(w)) < 2e-5
+    if name == "denoising":
+        return
+    gold = np.load(f"{golden_dir}/spectral.npz")
+    gz, gw = torch.from_numpy(gold[f"{name}_z"]).cuda(), torch.from_numpy(gold[f"{name}_w"]).cuda()
+    sp = lambda t: t[:, ::5].cpu()                                          # noqa: E731
+    assert rel(sp(op.At(gw)), torch.from_numpy(gold[f"{name}_At"])) < 2e-5
+    assert rel(sp(op.A_pinv_eta(gw, 0.3)), torch.from_numpy(gold[f"{name}_A_pinv_eta"])) < 2e-5
+    assert rel(op.add_zeros(gw)[:, ::7].cpu(), torch.from_numpy(gold[f"{name}_add_zeros"])) == 0.0
+    if name in ("inpainting", "cs_walshhadamard"):                          # permutations (+ FWHT): unique
+        assert rel(sp(op.Vt(x)), torch.from_numpy(gold[f"{name}_Vt"])) < 2e-6
+        assert rel(sp(op.V(gz)), torch.from_numpy(gold[f"{name}_V"])) < 2e-6
+        assert rel(op.U(gw).cpu(), torch.from_numpy(gold[f"{name}_U"])) == 0.0
+
+
+@pytest.mark.parametrize("B,C,H,gn", [(2, 128, 64, True), (1, 64, 32, False), (3, 128, 32, True)])
+def test_small_cout_output_conv(hip, B, C, H, gn):
+    """conv_out of the celeba Model (128 -> 3, GroupNorm + swish fused, NCHW result) on the vector-ALU kernel."""
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, C, H, H, generator=g)
+    w = torch.randn(3, C, 3, 3, generator=g) * (9 * C) ** -0.5
+    b = torch.randn(3, generator=g)
+    sc, sh = torch.randn(B, C, generator=g), torch.randn(B, C, generator=g)
+    act = F.silu(x * sc[:, :, None, None] + sh[:, :, None, None]) if gn else x
+    ref = F.conv2d(act, w, b, padding=1)
+    got = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().cuda(), ops.pack_conv_weight(w.cuda()), 3, 3, bias=b.cuda(),
+                     gn=(sc.cuda().contiguous(), sh.cuda().contiguous()) if gn else None, gn_silu=True, out_nchw=True)
+    torch.cuda.synchronize()
+    assert got.shape == (B, 3, H, H)
+    assert rel(got, ref) < 2e-6
+
+
+def test_conv_in_as_im2col_gemm(hip):
+    """conv_in (3 -> 128, 3x3) as im2col (27 taps in one 32-wide K chunk) + 1x1 convolution."""
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(2, 3, 64, 64, generator=g)
+    w = torch.randn(128, 3, 3, 3, generator=g) * 27 ** -0.5
+    b = torch.randn(128, generator=g)
+    col = ops.nchw_im2col3x3_pad(x.cuda(), 32)
+    out = ops.conv2d(col, ops.pack_conv_in_weight_im2col(w.cuda(), 32), 128, 1, bias=b.cuda(), emit_stats=True)
+    torch.cuda.synchronize()
+    assert rel(out.t.cpu().permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1)) < 2e-6
+    assert out.stats is not None

@@ -17,7 +17,11 @@ OUT = os.path.join(ROOT, "tools", "_build")
 VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16_NO_MAIN"],
             "ne_nowl": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_WLOAD"], "ne_nosync": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_SYNC"],
             "ne_nofrag": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG"],
-            "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"]}
+            "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
+            "ne_burst": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_ILV=0"], "ne_prio": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_PRIO_HALF"],
+            "burst": ["-DDDNM_P16_ILV=0"], "prio": ["-DDDNM_P16_PRIO_HALF"]}
+if os.environ.get("ONLY"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 for i, a in enumerate(extra):
     VARIANTS[f"x{i}"] = a.split(",")
