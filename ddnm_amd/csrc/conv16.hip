@@ -33,6 +33,12 @@ struct Conv16Args {
     int Hs, Ws;                                // source resolution (H/2 when ups)
 };
 
+#ifndef DDNM_P16_XPREF
+#define DDNM_P16_XPREF 0            // build-time probe switch: 1 = read the next step's pixel fragments before its barrier
+#endif
+#ifndef DDNM_P16_LATE_DMA
+#define DDNM_P16_LATE_DMA 1         // build-time probe switch: 0 = request the next step's tiles right after the barrier
+#endif
 #ifndef DDNM_P16_ILV
 #define DDNM_P16_ILV 1              // build-time probe switch (tools/conv16_probe.py): 0 = read burst before the MFMAs
 #endif
@@ -210,7 +216,11 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto mfma_step = [&](int toff, int hb, int wb) {
+#if DDNM_P16_XPREF
+    half8 bpre[MT];                       // pixel fragments (k-step 0) of the UPCOMING step, read under the previous step's tail
+    bool have_pre = false;
+#endif
+    auto mfma_step = [&](int toff, int hb, int wb, auto&& after_first_kstep, int toff_next = -1, int hb_next = 0) {
         // byte offsets into `lds`; the buffer bases are multiples of 128, so the k-step XOR (bits 5-6) commutes
         int pb[MT], wo[NT];
 #pragma unroll
@@ -224,8 +234,16 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         half8 a[2][NT], b[2][MT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[0][j] = *reinterpret_cast<const half8*>(lds + wo[j]);
+#if DDNM_P16_XPREF
+        if (have_pre) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
+            for (int i = 0; i < MT; ++i) b[0][i] = bpre[i];
+        } else
+#endif
+        {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #ifdef DDNM_P16_NO_FRAG
@@ -240,6 +258,18 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) b[nxt][i] = *reinterpret_cast<const half8*>(lds + (pb[i] ^ ((ks + 1) << 5)));
             }
+#if DDNM_P16_XPREF
+            if (ks == 3 && toff_next >= 0) {
+                // the next step's pixel fragments do not depend on the tiles still in flight (the halo of this chunk, or the
+                // next chunk's halo that landed -- and was activated -- several barriers ago): read them under this
+                // step's last MFMAs instead of behind the next barrier
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int q = q0[i] + toff_next;
+                    bpre[i] = *reinterpret_cast<const half8*>(lds + q * C16_ROWB + ((kh ^ ((q >> 1) & 7)) << 4) + hb_next * G::HBYTES);
+                }
+            }
+#endif
             // 9-tap kernels: one LDS read of the next k-step behind each of the first MFMAs (-4 % vs a read burst up
             // front); the 1-tap GEMM form measured better with the burst (its steps are dominated by the tile loads)
             constexpr bool ILV = DDNM_P16_ILV && TAPS == 9 && MT * NT >= MT + NT;
@@ -258,7 +288,14 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
                 if constexpr (MT * NT > MT + NT) __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                after_first_kstep();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+#if DDNM_P16_XPREF
+        have_pre = toff_next >= 0;
+#endif
     };
 
     // ---- K loop over (chunk, tap) steps of this split-K slice, then the fused 1x1 shortcut's chunks
@@ -300,13 +337,26 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #ifndef DDNM_P16_NO_SYNC
             __syncthreads();           // this step's tiles have landed (every wave's), the other buffers are free
 #endif
-            if (tap + 1 < TAPS) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
-            else if (more) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((c + 1) * C16_KC), wb ^ 1);
-            if (tap == 0 && more) {
-                issue_main_halo(c + 1, hb ^ 1);
-                if (fuse_gn) load_gn(c + 1);
-            }
-            mfma_step(toff, hb, wb);
+            auto issue_next = [&]() {
+                if (tap + 1 < TAPS) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
+                else if (more) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((c + 1) * C16_KC), wb ^ 1);
+                if (tap == 0 && more) {
+                    issue_main_halo(c + 1, hb ^ 1);
+                    if (fuse_gn) load_gn(c + 1);
+                }
+            };
+            // upcoming step (for the cross-step fragment prefetch): next tap of this chunk, or tap 0 of the next chunk
+            int toff_n = -1, hb_n = hb;
+            if (tap + 1 < TAPS) toff_n = kx == 2 ? toff + HWd - 2 : toff + 1;
+            else if (more) { toff_n = 0; hb_n = hb ^ 1; }
+#if DDNM_P16_LATE_DMA
+            // the next step's tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
+            // loads) no longer sits between the barrier and the first fragment reads
+            mfma_step(toff, hb, wb, issue_next, toff_n, hb_n);
+#else
+            issue_next();
+            mfma_step(toff, hb, wb, [] {}, toff_n, hb_n);
+#endif
             // the next chunk's halo landed before this step's barrier (vmcnt(0) at tap 1): activate one 8-row piece per
             // tap while this step's MFMAs drain
             if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) act_group(tap - 1, hb ^ 1);
@@ -335,7 +385,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ch + 1 < s_end) issue_skip(ch + 1, hb ^ 1, wb ^ 1);
-            mfma_step(HWd + 1, hb, wb);
+            mfma_step(HWd + 1, hb, wb, [] {});
             wb ^= 1;
             hb ^= 1;
         }

@@ -5,8 +5,9 @@
 //
 //   workgroup = 256 threads = an 8 x 32 pixel patch, one output pixel per thread, Cout <= 4 accumulators each;
 //   per 32-channel chunk the (8+2) x (32+2) halo goes through LDS with the GroupNorm affine + swish applied on the
-//   way (zero padding AFTER the activation, like the reference); its 9 x Cout x 32 weights sit next to it and are
-//   read as wave-wide broadcasts; the 9 taps read the halo at shifted rows (pitch 36 floats: conflict-free float4).
+//   way (zero padding AFTER the activation, like the reference); the 9 taps read it at shifted rows (pitch 36 floats:
+//   conflict-free float4).  The weights are wave-uniform: they are read with SCALAR loads (s_load_dwordx4 through the
+//   constant cache) and enter the FMAs as SGPR operands -- one LDS read per 12 FMAs instead of four.
 #include "conv_common.h"
 
 constexpr int CS_TH = 8, CS_TW = 32, CS_KC = 32, CS_PITCH = 36, CS_MAXCO = 4;
@@ -14,7 +15,6 @@ constexpr int CS_NP = (CS_TH + 2) * (CS_TW + 2);
 
 __global__ __launch_bounds__(256) void conv3x3_small_cout_f32_kernel(const ddnm_conv_desc d, int tiles_x, int tiles_per_img) {
     __shared__ __attribute__((aligned(16))) float Hs[CS_NP * CS_PITCH];
-    __shared__ __attribute__((aligned(16))) float Ws[9 * CS_MAXCO * CS_KC];
     const int tid = threadIdx.x;
     const int img = blockIdx.x / tiles_per_img, t = blockIdx.x - img * tiles_per_img;
     const int ty0 = (t / tiles_x) * CS_TH, tx0 = (t % tiles_x) * CS_TW;
@@ -40,24 +40,18 @@ __global__ __launch_bounds__(256) void conv3x3_small_cout_f32_kernel(const ddnm_
             }
             *reinterpret_cast<f32x4*>(&Hs[r * CS_PITCH + c4 * 4]) = v;
         }
-        // weights of this chunk: Ws[(tap*Cout + o)*32 + c] = W[o][tap][cb + c]
-        for (int i = tid; i < 9 * d.Cout * CS_KC; i += 256) {
-            const int c = i & (CS_KC - 1), to = i >> 5;
-            const int tap = to / d.Cout, o = to - tap * d.Cout;
-            Ws[i] = d.weight[((size_t)o * 9 + tap) * Cin + cb + c];
-        }
         __syncthreads();
+        const float* __restrict__ wchunk = d.weight + cb;             // W[o][tap][cb + c], wave-uniform addresses
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float* hp = &Hs[((py + tap / 3) * (CS_TW + 2) + px + tap % 3) * CS_PITCH];
-            const float* wp = &Ws[tap * d.Cout * CS_KC];
 #pragma unroll
             for (int k4 = 0; k4 < CS_KC / 4; ++k4) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(hp + k4 * 4);
 #pragma unroll
                 for (int o = 0; o < CS_MAXCO; ++o) {
                     if (o < d.Cout) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + o * CS_KC + k4 * 4);    // wave-wide broadcast
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(wchunk + ((size_t)o * 9 + tap) * Cin + k4 * 4);   // scalar load
                         acc[o] = fmaf(a.x, w.x, acc[o]);
                         acc[o] = fmaf(a.y, w.y, acc[o]);
                         acc[o] = fmaf(a.z, w.z, acc[o]);

@@ -190,6 +190,8 @@ class EncoderUNetModel:
                 n = f"{prefix}.{j}"
                 if L[0] == "conv":
                     conv(n, g(n + ".weight"), cin_pad=CIN_PAD)
+                    if 9 * L[1] <= CIN_PAD:       # 3 input channels: the 27 taps fit one 32-wide K chunk (see models.py)
+                        w[n + ".weight.im2col"] = ops.pack_conv_in_weight_im2col(g(n + ".weight"), CIN_PAD)
                 elif L[0] == "res":
                     for norm in ("in_layers.0", "out_layers.0"):
                         w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
@@ -297,11 +299,14 @@ class EncoderUNetModel:
         emb = ops.linear(emb, w["time_embed.0.weight"], w["time_embed.0.bias"])
         emb = ops.linear(emb, w["time_embed.2.weight"], w["time_embed.2.bias"], silu_in=True)
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
-        h = ops.nchw_to_nhwc_pad(x.float().contiguous(), CIN_PAD)
+        im2col = "input_blocks.0.0.weight.im2col" in w
+        h = (ops.nchw_im2col3x3_pad if im2col else ops.nchw_to_nhwc_pad)(x.float().contiguous(), CIN_PAD)
         for prefix, layers in self._walk():
             for j, Ld in enumerate(layers):
                 n = f"{prefix}.{j}"
-                if Ld[0] == "conv":
+                if Ld[0] == "conv" and im2col:
+                    h = ops.conv2d(h, w[n + ".weight.im2col"], Ld[2], 1, bias=w[n + ".bias"], emit_stats=True)
+                elif Ld[0] == "conv":
                     h = ops.conv2d(h, w[n + ".weight"], Ld[2], 3, bias=w[n + ".bias"], emit_stats=True)
                 elif Ld[0] == "res":
                     h = self._res(n, Ld, h, film_all, tape)
@@ -312,11 +317,16 @@ class EncoderUNetModel:
         gn = self._gn(h, "out.0", keep=kp)
         C, HW = self.final_ch, self.pool_sp ** 2
         T, nh = HW + 1, self.final_ch // self.head_ch
-        X = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
+        # the B*T = B*65 token rows are padded to a multiple of 64 (zero rows) so that the two projections of the pool run
+        # on the MFMA GEMM tiles instead of the one-thread-per-output fallback (2 x 0.94 ms per step at B = 8)
+        Mp = (B * T + 63) // 64 * 64
+        X = torch.empty(Mp, C, dtype=torch.float32, device=x.device)
+        if Mp > B * T:
+            X[B * T:].zero_()
         check(L.ddnm_pool_tokens_f32(_p(h.t), _p(gn[0]), _p(gn[1]), _p(w["pool.pos"]), _p(X), B, HW, C, ops._stream()),
               "ddnm_pool_tokens_f32")
-        qkv = torch.empty(B, T, 3 * C, dtype=torch.float32, device=x.device)
-        ops.bgemm(X, w["pool.qkv.weight"], qkv, B * T, 3 * C, C, lda=C, ldb=C, ldc=3 * C, transb=True,
+        qkv = torch.empty(Mp, 3 * C, dtype=torch.float32, device=x.device)
+        ops.bgemm(X, w["pool.qkv.weight"], qkv, Mp, 3 * C, C, lda=C, ldb=C, ldc=3 * C, transb=True,
                   D=w["pool.qkv.bias"], ldd=0, beta=1.0)
         P = torch.empty(B, nh, T, dtype=torch.float32, device=x.device)
         a0 = torch.empty(B, C, dtype=torch.float32, device=x.device)
@@ -399,11 +409,14 @@ class EncoderUNetModel:
         C, HW = self.final_ch, self.pool_sp ** 2
         T, nh = HW + 1, self.final_ch // self.head_ch
         da0 = ops.linear(dlogits, w["pool.c.weight_t"], None)
-        dqkv = torch.empty_like(qkv)
+        dqkv = torch.empty_like(qkv)                     # [Mp, 3C]: B*T token rows + zero padding rows (see forward)
+        Mp = qkv.shape[0]
+        if Mp > B * T:
+            dqkv[B * T:].zero_()
         check(L.ddnm_pool_attn_bwd_f32(_p(qkv), _p(P), _p(da0), _p(dqkv), B, T, C, nh, ops._stream()),
               "ddnm_pool_attn_bwd_f32")
-        dX = torch.empty(B, T, C, dtype=torch.float32, device=x.device)
-        ops.bgemm(dqkv, w["pool.qkv.weight"], dX, B * T, C, 3 * C, lda=3 * C, ldb=C, ldc=C, transb=False)
+        dX = torch.empty(Mp, C, dtype=torch.float32, device=x.device)
+        ops.bgemm(dqkv, w["pool.qkv.weight"], dX, Mp, C, 3 * C, lda=3 * C, ldb=C, ldc=C, transb=False)
         dact = torch.empty_like(h_pre)
         check(L.ddnm_pool_tokens_bwd_f32(_p(dX), _p(dact), B, HW, C, ops._stream()), "ddnm_pool_tokens_bwd_f32")
         dh = self._gn_bwd(h_pre, dact, kp, True)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Classifier guidance of BASELINE config 5 alone: forward + input-gradient backward at B = 8 (rocprofv3 target)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ddnm_amd.guided_diffusion.classifier import classifier_defaults, create_classifier, make_cond_fn  # noqa: E402
+
+B = int(os.environ.get("B", "8"))
+kw = classifier_defaults()
+kw["image_size"] = 256
+clf = create_classifier(**kw)
+g = torch.Generator().manual_seed(4321)
+clf.load_state_dict({k: (torch.randn(v, generator=g) * (1.0 / max(1, int(torch.tensor(v[1:]).prod()))) ** 0.5 if len(v) > 1
+                         else (1.0 + 0.1 * torch.randn(v, generator=g) if k.endswith("weight") else 0.05 * torch.randn(v, generator=g)))
+                     for k, v in clf.state_dict_shapes().items()})
+clf.convert_to_fp16()
+fn = make_cond_fn(clf, 1.0)
+x = torch.randn(B, 3, 256, 256, device="cuda")
+t = torch.full((B,), 500.0, device="cuda")
+y = torch.full((B,), 951, dtype=torch.long, device="cuda")
+for _ in range(2):
+    fn(x, t, y)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for _ in range(n):
+    fn(x, t, y)
+torch.cuda.synchronize()
+print(f"classifier forward + input gradient at B={B}: {(time.perf_counter() - t0) / n * 1e3:.2f} ms")

@@ -11,7 +11,8 @@ import pandas as pd
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNEL = "conv3x3_halo_f32_kernel<2, 2, 2, 2>"
+KERNEL = os.environ.get("PMC_KERNEL", "conv3x3_halo_f32_kernel<2, 2, 2, 2>")
+PASSES = os.environ.get("PMC_PASSES", "2 forwards at B=8 per PMC pass")
 
 
 def pivot(path):
@@ -38,11 +39,15 @@ def main(root, out_json, out_md, stats_db=None):
     n = len(m)
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs issue MFMA
     util = (m.SQ_VALU_MFMA_BUSY_CYCLES / (1024.0 * m.GRBM_GUI_ACTIVE / 8.0))
+    lds = {}
+    if "SQ_LDS_BANK_CONFLICT" in m.columns and "SQ_LDS_IDX_ACTIVE" in m.columns:
+        lds = {"lds_bank_conflict_frac": float(m.SQ_LDS_BANK_CONFLICT.sum() / max(1.0, m.SQ_LDS_IDX_ACTIVE.sum())),
+               "lds_bank_conflict_note": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE: extra LDS-array cycles per LDS-array cycle"}
     fetch_b = f.FETCH_SIZE * 1024.0 * 2.0
     write_b = w.WRITE_SIZE * 1024.0
     from ddnm_amd import build
     res = {
-        "kernel": KERNEL, "launches_per_forward": n // 2, "passes": "2 forwards at B=8 per PMC pass",
+        "kernel": KERNEL, "launches_in_pass": n, "passes": PASSES,
         # digest of the sources the profiled binary was built from: bench.py reports these figures only for a loaded
         # library with the same digest (the r01 file went stale the moment a kernel changed)
         "source_digest": build._digest(),
@@ -54,6 +59,7 @@ def main(root, out_json, out_md, stats_db=None):
         "note": "FETCH_SIZE x2 (gfx950 half-count of 16 B/lane reads), WRITE_SIZE exact (checked: 128->128 @256^2 "
                 "launch writes 266240 KiB = output 262144 KiB + GN partials 4096 KiB)",
     }
+    res.update(lds)
     json.dump(res, open(out_json, "w"), indent=1)
     lines = ["# PMC passes on the dominant kernel (rocprofv3 --pmc, separate runs)", "",
              "```", json.dumps(res, indent=1), "```", "", "| grid (threads) | launches | MFMA busy | FETCH MB (x2) | WRITE MB |",
