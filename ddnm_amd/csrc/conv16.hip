@@ -33,6 +33,12 @@ struct Conv16Args {
     int Hs, Ws;                                // source resolution (H/2 when ups)
 };
 
+#ifndef DDNM_P16_ACT_MID
+#define DDNM_P16_ACT_MID 0          // build-time probe switch: 1 = activate the next halo piece in the middle of the MFMA stream (measured: no gain)
+#endif
+#ifndef DDNM_P16_EARLY_RES
+#define DDNM_P16_EARLY_RES 1        // build-time probe switch: 0 = load the residual tile after the LDS staging
+#endif
 #ifndef DDNM_P16_XPREF
 #define DDNM_P16_XPREF 0            // build-time probe switch: 1 = read the next step's pixel fragments before its barrier
 #endif
@@ -220,7 +226,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     half8 bpre[MT];                       // pixel fragments (k-step 0) of the UPCOMING step, read under the previous step's tail
     bool have_pre = false;
 #endif
-    auto mfma_step = [&](int toff, int hb, int wb, auto&& after_first_kstep, int toff_next = -1, int hb_next = 0) {
+    auto mfma_step = [&](int toff, int hb, int wb, auto&& after_first_kstep, auto&& after_second_kstep, int toff_next = -1,
+                         int hb_next = 0) {
         // byte offsets into `lds`; the buffer bases are multiples of 128, so the k-step XOR (bits 5-6) commutes
         int pb[MT], wo[NT];
 #pragma unroll
@@ -292,6 +299,10 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
                 after_first_kstep();
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (ks == 1) {
+                after_second_kstep();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #if DDNM_P16_XPREF
         have_pre = toff_next >= 0;
@@ -349,17 +360,25 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             int toff_n = -1, hb_n = hb;
             if (tap + 1 < TAPS) toff_n = kx == 2 ? toff + HWd - 2 : toff + 1;
             else if (more) { toff_n = 0; hb_n = hb ^ 1; }
+            // the next chunk's halo landed before this step's barrier (vmcnt(0) at tap 1): one 8-row piece of it is
+            // activated per tap -- in the middle of the step's MFMA stream (ACT_MID), where the vector ALU is otherwise idle
+            auto act_next = [&]() {
+                if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) act_group(tap - 1, hb ^ 1);
+            };
 #if DDNM_P16_LATE_DMA
             // the next step's tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
             // loads) no longer sits between the barrier and the first fragment reads
-            mfma_step(toff, hb, wb, issue_next, toff_n, hb_n);
+#if DDNM_P16_ACT_MID
+            mfma_step(toff, hb, wb, issue_next, act_next, toff_n, hb_n);
+#else
+            mfma_step(toff, hb, wb, issue_next, [] {}, toff_n, hb_n);
+            act_next();
+#endif
 #else
             issue_next();
-            mfma_step(toff, hb, wb, [] {}, toff_n, hb_n);
+            mfma_step(toff, hb, wb, [] {}, [] {}, toff_n, hb_n);
+            act_next();
 #endif
-            // the next chunk's halo landed before this step's barrier (vmcnt(0) at tap 1): activate one 8-row piece per
-            // tap while this step's MFMAs drain
-            if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) act_group(tap - 1, hb ^ 1);
             wb ^= 1;
             if (++kx == 3) { kx = 0; toff += HWd - 2; } else { ++toff; }
         }
@@ -385,10 +404,38 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (ch + 1 < s_end) issue_skip(ch + 1, hb ^ 1, wb ^ 1);
-            mfma_step(HWd + 1, hb, wb, [] {});
+            mfma_step(HWd + 1, hb, wb, [] {}, [] {});
             wb ^= 1;
             hb ^= 1;
         }
+    }
+    // residual tile of the epilogue: requested NOW, before the barrier and the LDS transposition, so that its HBM
+    // latency overlaps them (nothing else hides it with one workgroup per CU)
+    constexpr int ITS = MT * 32 / 8;                 // lane -> (pixel = it*8 + lane/8, 8 channels = piece lane%8)
+    const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* const out = reinterpret_cast<_Float16*>(d.out);
+    const int cbase = n_tile * C16_BN + wn * 64;
+    const bool wave_on = cbase < d.Cout;            // Cout % 64 == 0: a wave's 64-channel slice is all in or all out
+    const int chn = cbase + lpiece * 8;
+    int opix[ITS];
+    uint4 rv[ITS];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int m = wm * MT * 32 + it * 8 + lrow;
+        int pix, rpix;
+        if (TAPS == 9) {
+            const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
+            pix = (img * d.H + oy) * d.W + ox;
+            rpix = d.res_ups ? (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1) : pix;
+        } else {
+            pix = m_tile * BM + m;
+            rpix = pix;
+            if (pix >= p.M) pix = -1;
+        }
+        if (!wave_on) pix = -1;
+        opix[it] = pix;
+        rv[it] = uint4{0u, 0u, 0u, 0u};
+        if (DDNM_P16_EARLY_RES && p.ksplit == 1 && WNW == 4 && res && pix >= 0) rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
     }
     __syncthreads();                   // all fragment reads done: LDS becomes the epilogue's staging area
 
@@ -422,8 +469,6 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         }
         return;
     }
-    const int cbase = n_tile * C16_BN + wn * 64;
-    const bool wave_on = cbase < d.Cout;            // Cout % 64 == 0: a wave's 64-channel slice is all in or all out
     if (p.ksplit > 1) {
         float* ws = d.workspace + (size_t)slice * p.M * d.Cout;
         if (!wave_on) return;
@@ -448,56 +493,44 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     char* const stage = lds + wave * (MT * 32) * C16_EPITCH;
     float* const stat_lds = reinterpret_cast<float*>(lds + 8 * (MT * 32) * C16_EPITCH);
     if (wave_on) {
-        f32x4 bias4[NT][4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j) {
+            f32x4 bias4[4];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int ch = cbase + j * 32 + 8 * rg + 4 * kh;
-                bias4[j][rg] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias4[rg] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
-                    const f32x4 b4 = bias4[j][rg];
+                    const f32x4 b4 = bias4[rg];
                     char* dst = stage + (i * 32 + (lane & 31)) * C16_EPITCH + (j * 32 + 8 * rg + 4 * kh) * 2;
                     half4 h = {(_Float16)(acc[i][j][4 * rg] + b4.x), (_Float16)(acc[i][j][4 * rg + 1] + b4.y),
                                (_Float16)(acc[i][j][4 * rg + 2] + b4.z), (_Float16)(acc[i][j][4 * rg + 3] + b4.w)};
                     *reinterpret_cast<half4*>(dst) = h;
                 }
+        }
     }
     // wave-local hand-off (each wave re-reads only its own staging region)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    constexpr int ITS = MT * 32 / 8;                 // lane -> (pixel = it*8 + lane/8, 8 channels = piece lane%8)
-    const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
-    _Float16* const out = reinterpret_cast<_Float16*>(d.out);
-    const int chn = cbase + lpiece * 8;
-    int opix[ITS];
-    uint4 rv[ITS];
+#if !DDNM_P16_EARLY_RES
 #pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int m = wm * MT * 32 + it * 8 + lrow;
-        int pix, rpix;
-        if (TAPS == 9) {
-            const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
-            pix = (img * d.H + oy) * d.W + ox;
-            rpix = d.res_ups ? (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1) : pix;
-        } else {
-            pix = m_tile * BM + m;
-            rpix = pix;
-            if (pix >= p.M) pix = -1;
+    for (int it = 0; it < ITS; ++it)
+        if (res && opix[it] >= 0) {
+            const int m = wm * MT * 32 + it * 8 + lrow;
+            int rpix = opix[it];
+            if (TAPS == 9 && d.res_ups) {
+                const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
+                rpix = (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1);
+            }
+            rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
         }
-        if (!wave_on) pix = -1;
-        opix[it] = pix;
-        rv[it] = uint4{0u, 0u, 0u, 0u};
-        if (res && pix >= 0) rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
-    }
+#endif
     float cs[8], cq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;

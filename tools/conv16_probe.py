@@ -21,7 +21,8 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_burst": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_ILV=0"], "ne_prio": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_PRIO_HALF"],
             "burst": ["-DDDNM_P16_ILV=0"], "prio": ["-DDDNM_P16_PRIO_HALF"],
             "ne_early": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_LATE_DMA=0"], "early": ["-DDDNM_P16_LATE_DMA=0"],
-            "ne_xpref": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_XPREF=1"], "xpref": ["-DDDNM_P16_XPREF=1"]}
+            "ne_xpref": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_XPREF=1"], "xpref": ["-DDDNM_P16_XPREF=1"],
+            "act_end": ["-DDDNM_P16_ACT_MID=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"]}
 if os.environ.get("ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round checkpoint on an MI355X box (run through gpurun from the repo root):
-#   full GPU test suite, the headline bench line, a rocprofv3 kernel trace of the same command and the three PMC
-#   passes over two forwards; summaries land in gpurun_out/ and are copied into profiles/ by hand.
+#   smoke, full GPU test suite, the headline bench line (with the c3 / c4 / c5 workloads), rocprofv3 kernel traces of
+#   the bench command and of the ADM fp16 forward, and the PMC passes (separate runs) over the celeba forward (fp32
+#   headline kernel) and the ADM forward (conv16); summaries land in gpurun_out/ and are copied into profiles/ by hand.
 # Every step runs under its own `timeout`: a faulting GPU once left rocprofv3 hanging for the whole remaining budget.
 set +e
 python - <<'PY' || { echo 'GPU sanity check failed: not running the checkpoint on this box'; exit 3; }
@@ -13,14 +14,19 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; echo 'smoke() failed: stopping before the long steps'; exit 4; }
 tail -1 gpurun_out/smoke.log
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-timeout 600 python bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
+if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6; fi
+timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
 cd /tmp
-rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/pmc_mfma /root/repo/gpurun_out/pmc_fetch /root/repo/gpurun_out/pmc_write
-timeout -k 10 420 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /root/repo/gpurun_out/prof_bench.log 2>&1
-timeout -k 10 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /root/repo/gpurun_out/pmc_mfma -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc1.log 2>&1
-timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc_fetch -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc2.log 2>&1
-timeout -k 10 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /root/repo/gpurun_out/pmc_write -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc3.log 2>&1
+rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/prof_adm16 /root/repo/gpurun_out/pmc_c2 /root/repo/gpurun_out/pmc16
+timeout -k 10 420 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-workloads > /root/repo/gpurun_out/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_adm16 -o adm -- python /root/repo/tools/adm_fwd.py 5 > /root/repo/gpurun_out/prof_adm16.log 2>&1
+for k in mfma fetch write; do
+  case $k in mfma) C="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
+  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d /root/repo/gpurun_out/pmc_c2/pmc_$k -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc_c2_$k.log 2>&1
+  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d /root/repo/gpurun_out/pmc16/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16_$k.log 2>&1
+done
 cd /root/repo
 python tools/prof_summary.py $(find gpurun_out/prof_bench -name "*.db" | head -1) gpurun_out/prof_bench_summary.md > /dev/null; head -12 gpurun_out/prof_bench_summary.md
-python tools/pmc_summary.py gpurun_out gpurun_out/pmc_dominant.json gpurun_out/pmc_dominant.md | tail -12
+python tools/prof_summary.py $(find gpurun_out/prof_adm16 -name "*.db" | head -1) gpurun_out/prof_adm16_summary.md > /dev/null; head -14 gpurun_out/prof_adm16_summary.md
+python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/pmc_c2_dominant.json gpurun_out/pmc_c2_dominant.md $(find gpurun_out/prof_bench -name "*.db" | head -1) | tail -8
+PMC_KERNEL="conv16_kernel<9, 4, 4>" PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/pmc16_conv16.json gpurun_out/pmc16_conv16.md $(find gpurun_out/prof_adm16 -name "*.db" | head -1) | tail -8
