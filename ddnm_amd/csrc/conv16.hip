@@ -717,6 +717,12 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
         ks = (int)(256 / tiles);
         if (ks > nchunks / 2) ks = nchunks / 2 > 0 ? nchunks / 2 : 1;      // keep >= 2 chunks per slice
         if (ks > 32) ks = 32;
+        // a 1x1 convolution with K <= 1024 is at most 16 steps: slicing it costs more (fp32 slabs + the reduction
+        // launch) than the idle CUs do (measured 1024 -> 1024 @16^2: 25.7 -> 17.7 us, 512 -> 512 @32^2: 32.8 -> 12.5 us)
+        if (pl->taps == 1 && nchunks <= 16 && hw % bm == 0) ks = 1;
+#ifdef DDNM_P16_KSCAP               // build-time probe: cap on the split-K factor
+        if (ks > DDNM_P16_KSCAP) ks = DDNM_P16_KSCAP;
+#endif
         if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;

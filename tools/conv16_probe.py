@@ -18,11 +18,8 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_nowl": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_WLOAD"], "ne_nosync": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_SYNC"],
             "ne_nofrag": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG"],
             "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
-            "ne_burst": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_ILV=0"], "ne_prio": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_PRIO_HALF"],
-            "burst": ["-DDDNM_P16_ILV=0"], "prio": ["-DDDNM_P16_PRIO_HALF"],
-            "ne_early": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_LATE_DMA=0"], "early": ["-DDDNM_P16_LATE_DMA=0"],
-            "ne_xpref": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_XPREF=1"], "xpref": ["-DDDNM_P16_XPREF=1"],
-            "act_end": ["-DDDNM_P16_ACT_MID=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"]}
+            "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None,
+            "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
 if os.environ.get("ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
@@ -33,7 +30,9 @@ os.makedirs(OUT, exist_ok=True)
 libs = {}
 for n, fl in VARIANTS.items():
     so = os.path.join(OUT, f"libp16_{n}.so")
-    if not os.path.exists(so) or BUILD_ONLY:
+    if n == "old":          # a previously built library of an older source (A/B inside one session)
+        assert os.path.exists(so), so
+    elif not os.path.exists(so) or BUILD_ONLY:
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + fl +
                        [os.path.join(CSRC, "conv16.hip"), "-o", so], check=True)
     if BUILD_ONLY:
@@ -48,7 +47,15 @@ dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
 B = 4
 print("shape                 " + " ".join(f"{n:>10s}" for n in libs) + "   (us)")
-for name, Cin, Cout, H, k, res in [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
+LOW = [("warm", 256, 256, 256, 3, 1), ("512->512@64 res", 512, 512, 64, 3, 1), ("512->1024@32", 512, 1024, 32, 3, 0),
+       ("1024->1024@32 res", 1024, 1024, 32, 3, 1), ("1024->1024@16 res", 1024, 1024, 16, 3, 1),
+       ("2048->1024@16", 2048, 1024, 16, 3, 0), ("1536->1024@32", 1536, 1024, 32, 3, 0)]
+ONE = [("warm", 256, 256, 256, 3, 1),
+       ("9216->1024@8 1x1", 9216, 1024, 8, 1, 0), ("1024->3072@32 1x1", 1024, 3072, 32, 1, 0),
+       ("1024->1024@16 1x1", 1024, 1024, 16, 1, 0), ("1024->3072@16 1x1", 1024, 3072, 16, 1, 0),
+       ("1024->1024@8 1x1", 1024, 1024, 8, 1, 0), ("1024->3072@8 1x1", 1024, 3072, 8, 1, 0),
+       ("512->1536@32 1x1", 512, 1536, 32, 1, 0), ("512->512@32 1x1", 512, 512, 32, 1, 0)]
+for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE}.get(os.environ.get("SHAPES"), None) or [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
                                    ("256->256@256 res", 256, 256, 256, 3, 1), ("256->256@256", 256, 256, 256, 3, 0),
                                    ("512->256@256", 512, 256, 256, 3, 0), ("1024->256@256", 1024, 256, 256, 3, 0),
                                    ("256->256@128 res", 256, 256, 128, 3, 1), ("512->512@128 res", 512, 512, 128, 3, 1),
@@ -59,7 +66,7 @@ for name, Cin, Cout, H, k, res in [("warm", 256, 256, 256, 3, 1), ("64->256@256 
     bias = torch.randn(Cout, device=dev)
     r = torch.randn(B, H, H, Cout, device=dev).half()
     out = torch.empty(B, H, H, Cout, device=dev, dtype=torch.float16)
-    stats = torch.empty(B * (H * H // 128) * Cout * 2, device=dev)
+    stats = torch.empty(B * max(H * H // 128, 64) * Cout * 2, device=dev)
     d = Conv16Desc()
     d.src, d.weight, d.bias, d.out, d.stats_out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), stats.data_ptr()
     d.res = r.data_ptr() if res else None
@@ -69,6 +76,17 @@ for name, Cin, Cout, H, k, res in [("warm", 256, 256, 256, 3, 1), ("64->256@256 
         d.gn_scale, d.gn_shift, d.gn_silu = gsc.data_ptr(), gsh.data_ptr(), 1
     row = []
     for n, lib in libs.items():
+        lib.ddnm_conv16_workspace_floats.restype = ctypes.c_int64
+        lib.ddnm_conv16_workspace_floats.argtypes = [ctypes.POINTER(Conv16Desc)]
+        lib.ddnm_conv16_stats_tiles.restype = ctypes.c_int32
+        lib.ddnm_conv16_stats_tiles.argtypes = [ctypes.POINTER(Conv16Desc)]
+        d.stats_out = stats.data_ptr() if lib.ddnm_conv16_stats_tiles(ctypes.byref(d)) > 0 else None
+        need = lib.ddnm_conv16_workspace_floats(ctypes.byref(d))
+        if need > 0:
+            ws = torch.empty(need, device=dev)
+            d.workspace, d.workspace_floats = ws.data_ptr(), need
+        else:
+            d.workspace, d.workspace_floats = None, 0
         for _ in range(2):
             assert lib.ddnm_conv16(ctypes.byref(d), stream) == 0
         torch.cuda.synchronize()

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round checkpoint on an MI355X box (run through gpurun from the repo root):
-#   smoke, full GPU test suite, the headline bench line (with the c3 / c4 / c5 workloads), rocprofv3 kernel traces of
-#   the bench command and of the ADM fp16 forward, and the PMC passes (separate runs) over the celeba forward (fp32
-#   headline kernel) and the ADM forward (conv16); summaries land in gpurun_out/ and are copied into profiles/ by hand.
+#   smoke, full GPU test suite, rocprofv3 kernel traces of the bench command and of the ADM fp16 forward, the PMC passes
+#   (separate runs) over the celeba forward (fp32 headline kernel) and the ADM forward (conv16), and LAST the headline
+#   bench line (with the c3 / c4 / c5 workloads); summaries land in gpurun_out/ and are copied into profiles/ by hand.
 # Every step runs under its own `timeout`: a faulting GPU once left rocprofv3 hanging for the whole remaining budget.
 set +e
 python - <<'PY' || { echo 'GPU sanity check failed: not running the checkpoint on this box'; exit 3; }
@@ -15,7 +15,6 @@ mkdir -p gpurun_out
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; echo 'smoke() failed: stopping before the long steps'; exit 4; }
 tail -1 gpurun_out/smoke.log
 if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6; fi
-timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
 cd /tmp
 rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/prof_adm16 /root/repo/gpurun_out/pmc_c2 /root/repo/gpurun_out/pmc16
 timeout -k 10 420 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-workloads > /root/repo/gpurun_out/prof_bench.log 2>&1
@@ -30,3 +29,7 @@ python tools/prof_summary.py $(find gpurun_out/prof_bench -name "*.db" | head -1
 python tools/prof_summary.py $(find gpurun_out/prof_adm16 -name "*.db" | head -1) gpurun_out/prof_adm16_summary.md > /dev/null; head -14 gpurun_out/prof_adm16_summary.md
 python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/pmc_c2_dominant.json gpurun_out/pmc_c2_dominant.md $(find gpurun_out/prof_bench -name "*.db" | head -1) | tail -8
 PMC_KERNEL="conv16_kernel<9, 4, 4>" PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/pmc16_conv16.json gpurun_out/pmc16_conv16.md $(find gpurun_out/prof_adm16 -name "*.db" | head -1) | tail -8
+# bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
+# (profiles/*_pmc_dominant_kernel.json): install this run's summaries first, then take the bench line
+cp gpurun_out/pmc_c2_dominant.json profiles/r02_pmc_dominant_kernel.json; cp gpurun_out/pmc_c2_dominant.md profiles/r02_pmc_dominant_kernel.md
+timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
