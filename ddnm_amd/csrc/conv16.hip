@@ -7,11 +7,11 @@
 //   * block tile 256 (or 128) pixels x 256 output channels, 8 waves as 2 (pixels) x 4 (channels), wave tile
 //     128 x 64 = 4 x 2 MFMA tiles of v_mfma_f32_32x32x16_f16: 6 ds_read_b128 per 8 MFMAs (the first-generation
 //     64 x 64 wave tile needed 8 per 8 and was LDS-read bound);
-//   * both operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass):
+//   * both operands go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (no staging registers, no ds_write pass):
 //     the LDS image is lane-linear [row][64 channels = 128 B]; bank conflicts of the fragment reads are removed
 //     by an XOR swizzle of the 16-byte piece index with (row >> 1) & 7, applied to the per-lane SOURCE address
 //     and to the read address (the destination of an LDS-DMA cannot be permuted);
-//   * zero padding and ragged tiles read a 128-byte zero page instead of branching;
+//   * zero padding and ragged tiles are out-of-range buffer offsets (the load returns zero) instead of branches;
 //   * MFMA operands are swapped (A = weights, B = pixels): a lane then owns ONE pixel and 4 consecutive
 //     channels per accumulator quad, which makes the epilogue's LDS transposition ds_write_b64 / ds_read_b128
 //     and every global store a full 16 bytes per lane (8 lanes = one 128-byte line).
@@ -31,16 +31,11 @@ struct Conv16Args {
     int TW, TW_log2, tiles_x, tiles_per_img;   // 3x3: 2-D patch TH x TW of one image; 1x1: unused
     int m_tiles, n_tiles, ksplit, M;           // M = B*H*W output pixels
     int Hs, Ws;                                // source resolution (H/2 when ups)
+    int wmajor;                                // workgroup order inside a slice: 1 = pixel tiles fastest (weight-heavy launch)
 };
 
-#ifndef DDNM_P16_ACT_MID
-#define DDNM_P16_ACT_MID 0          // build-time probe switch: 1 = activate the next halo piece in the middle of the MFMA stream (measured: no gain)
-#endif
 #ifndef DDNM_P16_EARLY_RES
 #define DDNM_P16_EARLY_RES 1        // build-time probe switch: 0 = load the residual tile after the LDS staging
-#endif
-#ifndef DDNM_P16_XPREF
-#define DDNM_P16_XPREF 0            // build-time probe switch: 1 = read the next step's pixel fragments before its barrier
 #endif
 #ifndef DDNM_P16_LATE_DMA
 #define DDNM_P16_LATE_DMA 1         // build-time probe switch: 0 = request the next step's tiles right after the barrier
@@ -65,7 +60,14 @@ struct C16Geom {
     static constexpr int HG_PER_WAVE = (HGROUPS + 7) / 8;
     static constexpr int HBYTES = HROWS * C16_ROWB;
     static constexpr int WBYTES = BN * C16_ROWB;                        // 32 KB (4 KB)
-    static constexpr int LDS_MAIN = 2 * HBYTES + 2 * WBYTES;
+    // buffers in flight: the 128-pixel kernels have LDS to spare and run where the weights stream through L2 from HBM
+    // (low resolutions: every weight byte is used by a handful of pixel tiles and a step's MFMAs are shorter than an L2
+    // round trip), so they keep TWO weight tiles ahead of the one being multiplied; the 1-tap GEMM form needs a new
+    // pixel tile per step as well
+    static constexpr int NWB = (MT == 2 && WNW == 4) ? 3 : 2;
+    static constexpr int NHB = (TAPS == 1 && MT == 2) ? 3 : 2;
+    static constexpr int LDS_TILES = NHB * HBYTES + NWB * WBYTES;
+    static constexpr int LDS_MAIN = LDS_TILES + 512;                    // + GroupNorm scale | shift of one 64-channel chunk
     static constexpr int LDS_EPI = WNW == 4 ? 8 * (MT * 32) * C16_EPITCH + 2 * C16_BN * 2 * 4 : 0;
     static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
@@ -86,16 +88,22 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     constexpr int BM = G::BM, NT = G::NT, BN = G::BN;
     __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];     // ONE shared object (keeps the DMA pipeline)
     char* const Hb = lds;
-    char* const Wb = lds + 2 * G::HBYTES;
+    char* const Wb = lds + G::NHB * G::HBYTES;
 
     const ddnm_conv16_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = WNW == 4 ? wave >> 2 : wave, wn = WNW == 4 ? wave & 3 : 0;
     const int kh = lane >> 5;
-    const int tile_id = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int n_tile = tile_id % p.n_tiles, m_tile = tile_id / p.n_tiles;
-    const int slice = blockIdx.y;
+    // Workgroup -> (slice, pixel tile, channel tile).  Consecutive `q` share an XCD (= one L2): the split-K slice is
+    // the slowest index, so an XCD reads only ITS slices' channel range of both operands; inside a slice the
+    // operand that is larger for this launch is the one NOT replicated over XCDs (weight-heavy low-resolution
+    // layers: the pixel tiles of one weight stream sit on one XCD; the old order made every XCD read every weight).
+    const int q = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tiles_mn = p.m_tiles * p.n_tiles;
+    const int slice = q / tiles_mn, t_mn = q - slice * tiles_mn;
+    const int n_tile = p.wmajor ? t_mn / p.m_tiles : t_mn % p.n_tiles;
+    const int m_tile = p.wmajor ? t_mn % p.m_tiles : t_mn / p.n_tiles;
     const int Cin = d.Cin;
 
     // ---- tile geometry
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     // ---- LDS-DMA source mapping.  One instruction moves 8 rows x 128 B; lane -> (row = 8*g + lane/8, piece lane%8),
     // and the piece it FETCHES is piece ^ swizzle(row) so that the linear image holds the swizzled layout.
     const int lrow = lane >> 3, lpiece = lane & 7;
-    int hoff[G::HG_PER_WAVE];           // source pixel index (element offset / Cin) or -1 -> zero page
+    int hoff[G::HG_PER_WAVE];           // source pixel index (element offset / Cin) or -1 -> out-of-range offset (zero)
     // logical piece (in halfs) this lane fetches: row = (wave + 8*gi)*8 + lrow, so (row >> 1) & 7 does not depend on gi
     const int lp8 = (lpiece ^ (((wave & 1) << 2) | (lrow >> 1))) * 8;
 #pragma unroll
@@ -179,12 +187,21 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     // 16-byte pieces it fetched (so it needs no barrier, only its own vmcnt wait, knows which rows are zero padding --
     // the reference pads the ACTIVATED tensor -- and which 8 channels it holds: lp8 .. lp8+7 of the chunk).
     const bool fuse_gn = TAPS == 9 && d.gn_scale != nullptr;
+    // The chunk's 64 scales and 64 shifts travel by LDS-DMA as well (wave 0, 16 lanes each) and are read back into
+    // registers one barrier later: a VGPR load inside the rolled tap loop makes the compiler wait with vmcnt(0) in
+    // front of every use, which would drain the request pipeline in each activated tap.
+    char* const Gb = lds + G::LDS_TILES;
     f32x4 gsc0, gsc1, gsh0, gsh1;
-    auto load_gn = [&](int c) {
-        const float* sc = d.gn_scale + (size_t)img * Cin + c * C16_KC + lp8;
-        const float* sh = d.gn_shift + (size_t)img * Cin + c * C16_KC + lp8;
-        gsc0 = *reinterpret_cast<const f32x4*>(sc); gsc1 = *reinterpret_cast<const f32x4*>(sc + 4);
-        gsh0 = *reinterpret_cast<const f32x4*>(sh); gsh1 = *reinterpret_cast<const f32x4*>(sh + 4);
+    auto issue_gn = [&](int c) {
+        if (wave == 0 && lane < 16) {
+            const unsigned nb = (unsigned)d.B * Cin * 4u, vo = ((unsigned)(img * Cin + c * C16_KC) * 4u) + lane * 16u;
+            bload16(make_rsrc(d.gn_scale, nb), vo, 0u, Gb);
+            bload16(make_rsrc(d.gn_shift, nb), vo, 0u, Gb + 256);
+        }
+    };
+    auto read_gn = [&]() {
+        gsc0 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4); gsc1 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4 + 16);
+        gsh0 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4); gsh1 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4 + 16);
     };
     auto act_group = [&](int gi, int hb) {
         if (wave + 8 * gi < G::HGROUPS && hoff[gi] >= 0) {
@@ -222,12 +239,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#if DDNM_P16_XPREF
-    half8 bpre[MT];                       // pixel fragments (k-step 0) of the UPCOMING step, read under the previous step's tail
-    bool have_pre = false;
-#endif
-    auto mfma_step = [&](int toff, int hb, int wb, auto&& after_first_kstep, auto&& after_second_kstep, int toff_next = -1,
-                         int hb_next = 0) {
+    auto mfma_step = [&](int toff, int hb, int wb, auto&& after_first_kstep) {
         // byte offsets into `lds`; the buffer bases are multiples of 128, so the k-step XOR (bits 5-6) commutes
         int pb[MT], wo[NT];
 #pragma unroll
@@ -236,21 +248,13 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             pb[i] = q * C16_ROWB + ((kh ^ ((q >> 1) & 7)) << 4) + hb * G::HBYTES;
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wo[j] = wa[j] + 2 * G::HBYTES + wb * G::WBYTES;
+        for (int j = 0; j < NT; ++j) wo[j] = wa[j] + G::NHB * G::HBYTES + wb * G::WBYTES;
         // explicit two-deep fragment pipeline: the 6 reads of k-step ks+1 are in flight under the 8 MFMAs of ks
         half8 a[2][NT], b[2][MT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[0][j] = *reinterpret_cast<const half8*>(lds + wo[j]);
-#if DDNM_P16_XPREF
-        if (have_pre) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) b[0][i] = bpre[i];
-        } else
-#endif
-        {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
-        }
+        for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #ifdef DDNM_P16_NO_FRAG
@@ -265,18 +269,6 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) b[nxt][i] = *reinterpret_cast<const half8*>(lds + (pb[i] ^ ((ks + 1) << 5)));
             }
-#if DDNM_P16_XPREF
-            if (ks == 3 && toff_next >= 0) {
-                // the next step's pixel fragments do not depend on the tiles still in flight (the halo of this chunk, or the
-                // next chunk's halo that landed -- and was activated -- several barriers ago): read them under this
-                // step's last MFMAs instead of behind the next barrier
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int q = q0[i] + toff_next;
-                    bpre[i] = *reinterpret_cast<const half8*>(lds + q * C16_ROWB + ((kh ^ ((q >> 1) & 7)) << 4) + hb_next * G::HBYTES);
-                }
-            }
-#endif
             // 9-tap kernels: one LDS read of the next k-step behind each of the first MFMAs (-4 % vs a read burst up
             // front); the 1-tap GEMM form measured better with the burst (its steps are dominated by the tile loads)
             constexpr bool ILV = DDNM_P16_ILV && TAPS == 9 && MT * NT >= MT + NT;
@@ -299,38 +291,53 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
                 after_first_kstep();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ks == 1) {
-                after_second_kstep();
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-#if DDNM_P16_XPREF
-        have_pre = toff_next >= 0;
-#endif
     };
 
-    // ---- K loop over (chunk, tap) steps of this split-K slice, then the fused 1x1 shortcut's chunks
+    // ---- K loop over (chunk, tap) steps of this split-K slice, then the fused 1x1 shortcut's chunks.
+    // Tiles are requested LA steps ahead of the step that multiplies them, into the buffer the step's barrier has just
+    // freed; the wait in front of a barrier therefore leaves exactly the younger request group in flight
+    // (`s_waitcnt vmcnt(GRP)`: VMEM operations complete in order, and the weight tile -- 4 requests per wave,
+    // unconditional -- is always the youngest part of a group).
+    constexpr int LA = G::NWB - 1;
+    constexpr int GRP = TAPS == 1 ? G::HG_PER_WAVE + 4 : 4;
+    static_assert(LA == 1 || (WNW == 4 && (TAPS == 9 || G::HGROUPS % 8 == 0)), "counted waits need fixed-size request groups");
     const int nchunks = Cin / C16_KC;
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
     const int SC = d.SC0 + d.SC1, nsk = d.skip0 ? SC / C16_KC : 0;
     const int s_begin = (int)((long)nsk * slice / p.ksplit), s_end = (int)((long)nsk * (slice + 1) / p.ksplit);
     const int n_main = c_end - c_begin, n_skip = s_end - s_begin;
-#ifdef DDNM_P16_PRIO_HALF        // probe: static priority for the later-dispatched half of the waves (MI355X_MICROARCH.md)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
+    const unsigned wrow = (unsigned)(TAPS * Cin);
     int hb = 0, wb = 0;
+    bool pend = false;                 // the previous step requested a group that may still be in flight
+    auto wait_tiles = [&]() {
+        if (LA == 2 && pend) {
+            if constexpr (GRP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
 #ifdef DDNM_P16_NO_MAIN
     if (false) {
 #else
     if (n_main > 0) {
 #endif
         issue_main_halo(c_begin, 0);
-        issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)(c_begin * C16_KC), 0);
+        if (fuse_gn) issue_gn(c_begin);
+        issue_w(r_w, wrow, (unsigned)(c_begin * C16_KC), 0);
+        if (LA == 2 && (TAPS == 9 || c_begin + 1 < c_end)) {
+            if (TAPS == 1) issue_main_halo(c_begin + 1, 1);
+            issue_w(r_w, wrow, (unsigned)(TAPS == 9 ? Cin + c_begin * C16_KC : (c_begin + 1) * C16_KC), 1);
+            pend = true;
+        }
         if (fuse_gn) {
-            load_gn(c_begin);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_tiles();                           // the first halo (this wave's pieces) and the parameters have landed
+            __builtin_amdgcn_s_barrier();
+            read_gn();
 #pragma unroll
             for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) act_group(gi, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // activated pieces are in LDS before the first step's barrier
         }
     }
 #pragma unroll 1
@@ -344,45 +351,45 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         // (rolled on purpose: unrolled, the compiler hoists 9 x 16 loop-invariant fragment addresses and spills)
 #pragma unroll 1
         for (int tap = 0; tap < TAPS; ++tap) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_tiles();
 #ifndef DDNM_P16_NO_SYNC
-            __syncthreads();           // this step's tiles have landed (every wave's), the other buffers are free
+            __builtin_amdgcn_s_barrier();           // this step's tiles have landed (every wave's); the oldest buffers are free
 #endif
             auto issue_next = [&]() {
-                if (tap + 1 < TAPS) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
-                else if (more) issue_w(r_w, (unsigned)(TAPS * Cin), (unsigned)((c + 1) * C16_KC), wb ^ 1);
-                if (tap == 0 && more) {
-                    issue_main_halo(c + 1, hb ^ 1);
-                    if (fuse_gn) load_gn(c + 1);
+                pend = false;
+                if (TAPS == 9) {
+                    if (tap == 0 && more) {         // next chunk's halo (older than this group's weight tile: landed by tap 1)
+                        issue_main_halo(c + 1, hb ^ 1);
+                        if (fuse_gn) issue_gn(c + 1);
+                    }
+                } else if (c + LA < c_end) {
+                    issue_main_halo(c + LA, hb + LA >= G::NHB ? hb + LA - G::NHB : hb + LA);
+                }
+                int t2 = tap + LA, c2 = c;
+                while (t2 >= TAPS) { t2 -= TAPS; ++c2; }
+                if (c2 < c_end) {
+                    issue_w(r_w, wrow, (unsigned)(t2 * Cin + c2 * C16_KC), wb + LA >= G::NWB ? wb + LA - G::NWB : wb + LA);
+                    pend = true;
                 }
             };
-            // upcoming step (for the cross-step fragment prefetch): next tap of this chunk, or tap 0 of the next chunk
-            int toff_n = -1, hb_n = hb;
-            if (tap + 1 < TAPS) toff_n = kx == 2 ? toff + HWd - 2 : toff + 1;
-            else if (more) { toff_n = 0; hb_n = hb ^ 1; }
-            // the next chunk's halo landed before this step's barrier (vmcnt(0) at tap 1): one 8-row piece of it is
-            // activated per tap -- in the middle of the step's MFMA stream (ACT_MID), where the vector ALU is otherwise idle
-            auto act_next = [&]() {
-                if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) act_group(tap - 1, hb ^ 1);
-            };
 #if DDNM_P16_LATE_DMA
-            // the next step's tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
+            // the next tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
             // loads) no longer sits between the barrier and the first fragment reads
-#if DDNM_P16_ACT_MID
-            mfma_step(toff, hb, wb, issue_next, act_next, toff_n, hb_n);
-#else
-            mfma_step(toff, hb, wb, issue_next, [] {}, toff_n, hb_n);
-            act_next();
-#endif
+            mfma_step(toff, hb, wb, issue_next);
 #else
             issue_next();
-            mfma_step(toff, hb, wb, [] {}, [] {}, toff_n, hb_n);
-            act_next();
+            mfma_step(toff, hb, wb, [] {});
 #endif
-            wb ^= 1;
+            // the next chunk's halo and parameters landed before this step's barrier (tap >= 1): one 8-row piece is
+            // activated per tap
+            if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) {
+                if (tap == 1) read_gn();
+                act_group(tap - 1, hb ^ 1);
+            }
+            wb = wb + 1 == G::NWB ? 0 : wb + 1;
             if (++kx == 3) { kx = 0; toff += HWd - 2; } else { ++toff; }
         }
-        hb ^= 1;
+        hb = hb + 1 == G::NHB ? 0 : hb + 1;
     }
     if (TAPS == 9 && n_skip > 0) {
         // fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's RAW
@@ -402,10 +409,11 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll 1
         for (int ch = s_begin; ch < s_end; ++ch) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (ch + 1 < s_end) issue_skip(ch + 1, hb ^ 1, wb ^ 1);
-            mfma_step(HWd + 1, hb, wb, [] {}, [] {});
-            wb ^= 1;
+            __builtin_amdgcn_s_barrier();
+            const int wbn = wb + 1 == G::NWB ? 0 : wb + 1;
+            if (ch + 1 < s_end) issue_skip(ch + 1, hb ^ 1, wbn);
+            mfma_step(HWd + 1, hb, wb, [] {});
+            wb = wbn;
             hb ^= 1;
         }
     }
@@ -775,8 +783,14 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     p.M = d->B * d->H * d->W;
     p.Hs = d->ups ? d->H / 2 : d->H;
     p.Ws = d->ups ? d->W / 2 : d->W;
+#ifndef DDNM_P16_WMAJOR_MAXM
+#define DDNM_P16_WMAJOR_MAXM 8
+#endif
+    // weight bytes > activation bytes, and few enough pixel tiles per weight stream that one XCD's CUs do not all pull
+    // the same weight lines at the same moment (32 sharers measured SLOWER than replicating the weights over XCDs)
+    p.wmajor = ((long)d->Cout * pl.taps > (long)p.M && pl.m_tiles <= DDNM_P16_WMAJOR_MAXM) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(pl.m_tiles * pl.n_tiles, pl.ksplit);
+    const dim3 grid(pl.m_tiles * pl.n_tiles * pl.ksplit);
     if (pl.small) {
         DDNM_LAUNCH((conv16_kernel<9, 1, 1>), grid, dim3(512), 0, s, p);
     } else if (pl.taps == 9) {

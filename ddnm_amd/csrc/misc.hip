@@ -24,11 +24,81 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     if (lane == 0) y[(size_t)b * N + n] = acc + (bias ? bias[n] : 0.f);
 }
 
+// Row-streaming form for the wide FiLM projection (all ResBlock emb_layers of the ADM UNet in one launch: N = 51712
+// rows of K = 1024 fp32 = 212 MB per forward, the x rows are a few KB).  A wave owns whole W rows and reads each ONCE
+// with 16-byte loads (next row in flight while the current one is multiplied); BT (4 or 8) x rows sit in registers in the
+// same lane layout (k = 256 i + 4 lane ...), so the only other traffic is one xor-reduction per (row, batch row).
+// Each (b, n) dot product is summed in an order that does not depend on B or on the launch geometry.
+template <int KV, int BT>           // K = 256 * KV
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                          int N, int silu_in) {
+    constexpr int K = 256 * KV;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (int b0 = 0; b0 < B; b0 += BT) {
+        f32x4 xv[BT][KV];
+#pragma unroll
+        for (int b = 0; b < BT; ++b)
+#pragma unroll
+            for (int i = 0; i < KV; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b0 + b < B) v = *reinterpret_cast<const f32x4*>(x + (size_t)(b0 + b) * K + i * 256 + lane * 4);
+                if (silu_in) v = f32x4{silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w)};
+                xv[b][i] = v;
+            }
+        f32x4 wv[KV], wn[KV];
+        int n = wave;
+        if (n < N) {
+#pragma unroll
+            for (int i = 0; i < KV; ++i) wv[i] = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + i * 256 + lane * 4);
+        }
+        for (; n < N; n += nwaves) {
+            const int nn = n + nwaves;
+            if (nn < N) {
+#pragma unroll
+                for (int i = 0; i < KV; ++i) wn[i] = *reinterpret_cast<const f32x4*>(W + (size_t)nn * K + i * 256 + lane * 4);
+            }
+            float acc[BT];
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < KV; ++i) {
+                    a += wv[i].x * xv[b][i].x;
+                    a += wv[i].y * xv[b][i].y;
+                    a += wv[i].z * xv[b][i].z;
+                    a += wv[i].w * xv[b][i].w;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                acc[b] = a;
+            }
+            if (lane < BT && b0 + lane < B) {
+                float v = acc[0];
+#pragma unroll
+                for (int b = 1; b < BT; ++b) v = lane == b ? acc[b] : v;
+                y[(size_t)(b0 + lane) * N + n] = v + (bias ? bias[n] : 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < KV; ++i) wv[i] = wn[i];
+        }
+    }
+}
+
 extern "C" int ddnm_linear_f32(const float* x, const float* W, const float* bias, float* y, int32_t B, int32_t K,
                                int32_t N, int32_t silu_in, void* stream) {
     if (!x || !W || !y || B <= 0 || K <= 0 || N <= 0) return DDNM_E_BADARG;
-    DDNM_LAUNCH(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, W, bias, y, K, N,
-                       silu_in);
+    hipStream_t s = (hipStream_t)stream;
+    if (N >= 4096 && (K == 512 || K == 1024) && (((uintptr_t)x | (uintptr_t)W) & 15) == 0) {
+        const int grid = 2048;                  // 8 workgroups (32 waves) per CU: >= 128 KB of W rows in flight per CU
+        if (K == 1024 && B <= 4) { DDNM_LAUNCH((linear_rows_kernel<4, 4>), dim3(grid), dim3(256), 0, s, x, W, bias, y, B, N, silu_in); }
+        else if (K == 1024) { DDNM_LAUNCH((linear_rows_kernel<4, 8>), dim3(grid), dim3(256), 0, s, x, W, bias, y, B, N, silu_in); }
+        else if (B <= 4) { DDNM_LAUNCH((linear_rows_kernel<2, 4>), dim3(grid), dim3(256), 0, s, x, W, bias, y, B, N, silu_in); }
+        else { DDNM_LAUNCH((linear_rows_kernel<2, 8>), dim3(grid), dim3(256), 0, s, x, W, bias, y, B, N, silu_in); }
+        return 0;
+    }
+    DDNM_LAUNCH(linear_kernel, dim3((N + 3) / 4, B), dim3(256), 0, s, x, W, bias, y, K, N, silu_in);
     return 0;
 }
 

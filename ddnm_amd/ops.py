@@ -361,11 +361,12 @@ def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=N
     return Act(out, stats, tiles)
 
 
-def conv16_out(src, weight, cout, bias=None):
-    """The network's output convolution on the fp16 path: 3x3, cout <= 32, fp32 NCHW result (unet.py:627-631,664)."""
+def conv16_out(src, weight, cout, bias=None, gn=None, gn_silu=True):
+    """The network's output convolution on the fp16 path: 3x3, cout <= 32, fp32 NCHW result (unet.py:627-631,664);
+    `gn` = (scale, shift) fuses the GroupNorm affine + swish of `out.0/out.1` into its loader like `conv16`."""
     src = src.t if isinstance(src, Act) else src
     B, H, W, _ = src.shape
-    d = _conv16_desc(src, weight, cout, 3, H, W, False, None, None, bias, None, False)
+    d = _conv16_desc(src, weight, cout, 3, H, W, False, None, None, bias, None, False, None, gn, gn_silu)
     d.out_nchw_f32 = 1
     out = torch.empty(B, cout, H, W, dtype=torch.float32, device=src.device)
     d.out = out.data_ptr()

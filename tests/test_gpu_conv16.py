@@ -149,6 +149,13 @@ def test_conv16_out_small_cout(hip):
     torch.cuda.synchronize()
     assert got.shape == (2, 6, 64, 64) and got.dtype == torch.float32
     assert rel(got, F.conv2d(x, w, b, padding=1)) < 2e-5
+    # GroupNorm affine + swish fused into its loader: bit-identical to the pre-pass route
+    sc, sh = torch.randn(2, 256, generator=g).cuda(), torch.randn(2, 256, generator=g).cuda()
+    pre = ops.gn_apply16(nhwc16(x), None, (sc, sh), True)
+    want = ops.conv16_out(pre, ops.pack_conv_weight16(w.cuda()), 6, bias=b.cuda())
+    fused = ops.conv16_out(nhwc16(x), ops.pack_conv_weight16(w.cuda()), 6, bias=b.cuda(), gn=(sc, sh), gn_silu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, want)
 
 
 @pytest.mark.parametrize("C0,C1,silu,pool", [(256, 0, True, False), (256, 128, True, False), (128, 0, False, False),

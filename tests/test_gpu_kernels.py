@@ -172,6 +172,20 @@ def test_linear(hip, silu):
     assert rel(got.cpu(), F.linear(xin, W, b)) < 2e-6
 
 
+@pytest.mark.parametrize("K", [512, 1024])
+def test_linear_wide_rows(hip, K):
+    """The wide FiLM projection (N >= 4096 rows) takes the row-streaming kernel: 5 batch rows cross its 4-row register
+    tile, and a row's result must not depend on how many rows the launch has."""
+    from ddnm_amd import ops
+    x, W, b = gen(5, K, seed=41), gen(4100, K, seed=42, scale=0.05), gen(4100, seed=43)
+    xin = x * torch.sigmoid(x)
+    got = ops.linear(x.cuda(), W.cuda(), b.cuda(), silu_in=True)
+    one = ops.linear(x[3:4].cuda().contiguous(), W.cuda(), b.cuda(), silu_in=True)
+    torch.cuda.synchronize()
+    assert rel(got.cpu(), F.linear(xin, W, b)) < 2e-6
+    assert torch.equal(got[3:4].cpu(), one.cpu())
+
+
 def test_timestep_embedding(hip):
     from ddnm_amd import ops
     from oracle import unet_celeba

@@ -18,7 +18,8 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_nowl": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_WLOAD"], "ne_nosync": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_SYNC"],
             "ne_nofrag": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG"],
             "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
-            "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None,
+            "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None, "nwb3": None, "maxm0": ["-DDDNM_P16_WMAJOR_MAXM=0"], "maxm16": ["-DDDNM_P16_WMAJOR_MAXM=16"],
+            "maxm64": ["-DDDNM_P16_WMAJOR_MAXM=64"],
             "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
 if os.environ.get("ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
@@ -30,7 +31,7 @@ os.makedirs(OUT, exist_ok=True)
 libs = {}
 for n, fl in VARIANTS.items():
     so = os.path.join(OUT, f"libp16_{n}.so")
-    if n == "old":          # a previously built library of an older source (A/B inside one session)
+    if fl is None:          # a previously built library of another source (A/B inside one session)
         assert os.path.exists(so), so
     elif not os.path.exists(so) or BUILD_ONLY:
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + fl +
@@ -46,6 +47,7 @@ if BUILD_ONLY:
 dev = "cuda"
 stream = torch.cuda.current_stream().cuda_stream
 B = 4
+flush = torch.empty(1 << 28, device=dev) if os.environ.get("COLD") == "1" else None      # 1 GiB
 print("shape                 " + " ".join(f"{n:>10s}" for n in libs) + "   (us)")
 LOW = [("warm", 256, 256, 256, 3, 1), ("512->512@64 res", 512, 512, 64, 3, 1), ("512->1024@32", 512, 1024, 32, 3, 0),
        ("1024->1024@32 res", 1024, 1024, 32, 3, 1), ("1024->1024@16 res", 1024, 1024, 16, 3, 1),
@@ -63,6 +65,10 @@ for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE}.get(os.environ.get("S
                                    ("1024->256@256 1x1", 1024, 256, 256, 1, 0)]:
     x = torch.randn(B, H, H, Cin, device=dev).half()
     w = (torch.randn(Cout, k * k, Cin, device=dev) * 0.02).half()
+    # COLD=1: rotate through copies of the weights (> 512 MB together) so that no launch finds them in L2 / MALL,
+    # like a layer inside a forward pass
+    ncopy = max(1, int(512e6 // (w.numel() * 2)) + 1) if os.environ.get("COLD") == "1" else 1
+    wcopies = [w] + [w.clone() for _ in range(min(ncopy, 64) - 1)]
     bias = torch.randn(Cout, device=dev)
     r = torch.randn(B, H, H, Cout, device=dev).half()
     out = torch.empty(B, H, H, Cout, device=dev, dtype=torch.float16)
@@ -89,10 +95,13 @@ for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE}.get(os.environ.get("S
             d.workspace, d.workspace_floats = None, 0
         for _ in range(2):
             assert lib.ddnm_conv16(ctypes.byref(d), stream) == 0
+        if len(wcopies) > 1:
+            flush.zero_()               # evict the freshly cloned weights from L2 / MALL
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
+        for it in range(10):
+            d.weight = wcopies[it % len(wcopies)].data_ptr()
             lib.ddnm_conv16(ctypes.byref(d), stream)
         e1.record()
         torch.cuda.synchronize()

@@ -39,6 +39,10 @@ SHAPES = [
     ("c256_256_32_gn_res", 8, 256, 0, 256, 32, 3, 1, 0, 1, 1, 0),
     ("c512_512_16_gn_res", 8, 512, 0, 512, 16, 3, 1, 0, 1, 1, 0),
     ("c512_512_8_gn_res", 8, 512, 0, 512, 8, 3, 1, 0, 1, 1, 0),
+    ("c256_256_32_plain", 8, 256, 0, 256, 32, 3, 1, 0, 0, 0, 0),
+    ("c768_256_32_gn", 8, 512, 256, 256, 32, 3, 1, 0, 1, 0, 0),
+    ("c1024_512_16_gn", 8, 512, 512, 512, 16, 3, 1, 0, 1, 0, 0),
+    ("c1024_512_8_gn", 8, 512, 512, 512, 8, 3, 1, 0, 1, 0, 0),
     ("c128_3_256_out", 8, 128, 0, 3, 256, 3, 1, 0, 1, 0, 0),
     ("c128_128_up256", 8, 128, 0, 128, 128, 3, 1, 1, 0, 0, 0),
     ("c128_128_down", 8, 128, 0, 128, 256, 3, 2, 0, 0, 0, 0),
