@@ -45,33 +45,45 @@ __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __r
         qf[ks] = *reinterpret_cast<const half8*>(base + (size_t)(q0 + ql) * row3 + ks * 16 + kh * 8);
 
     // tile loader mapping: piece index pi -> (key = pi / 8, 16-byte piece = pi % 8)
-    uint4 kreg[PPT], vreg[PPT];
+    // prefetch registers as NAMED values: as arrays they were demoted to scratch memory, which put a wait for the
+    // global loads + a scratch round trip in front of every tile (no prefetch at all)
+    uint4 k0, k1, k2, k3, v0, v1, v2, v3;
+    auto fetch1 = [&](int kt, int i, uint4& kr, uint4& vr) {
+        const int pi = tid + i * NT;
+        const int key = pi >> 3, pc = pi & 7;
+        const _Float16* r = base + (size_t)(kt * AT_KT + key) * row3 + pc * 8;
+        kr = *reinterpret_cast<const uint4*>(r + 64);
+        vr = *reinterpret_cast<const uint4*>(r + 128);
+    };
     auto fetch = [&](int kt) {
+        fetch1(kt, 0, k0, v0);
+        fetch1(kt, 1, k1, v1);
+        if constexpr (PPT > 2) {
+            fetch1(kt, 2, k2, v2);
+            fetch1(kt, 3, k3, v3);
+        }
+    };
+    auto stage1 = [&](int i, const uint4& kr, const uint4& vr) {
+        const int pi = tid + i * NT;
+        const int key = pi >> 3, pc = pi & 7;
+        *reinterpret_cast<uint4*>(Ks + key * 128 + ((pc ^ ((key >> 1) & 7)) << 4)) = kr;
+        // V^T: row = d, position of `key` inside its 16-key group permuted to [0-3, 8-11, 4-7, 12-15] so that the 8
+        // keys one lane-half contributes to an MFMA k-step are one contiguous 16-byte piece
+        const int k16 = key & 15;
+        const int pos = (key & ~15) | (k16 & 3) | ((k16 & 8) >> 1) | ((k16 & 4) << 1);
+        const half8 v = __builtin_bit_cast(half8, vr);
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int pi = tid + i * NT;
-            const int key = pi >> 3, pc = pi & 7;
-            const _Float16* r = base + (size_t)(kt * AT_KT + key) * row3 + pc * 8;
-            kreg[i] = *reinterpret_cast<const uint4*>(r + 64);
-            vreg[i] = *reinterpret_cast<const uint4*>(r + 128);
+        for (int e = 0; e < 8; ++e) {
+            const int d = pc * 8 + e;
+            *reinterpret_cast<_Float16*>(Vt + d * 128 + (((pos >> 3) ^ ((d >> 1) & 7)) << 4) + (pos & 7) * 2) = v[e];
         }
     };
     auto stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int pi = tid + i * NT;
-            const int key = pi >> 3, pc = pi & 7;
-            *reinterpret_cast<uint4*>(Ks + key * 128 + ((pc ^ ((key >> 1) & 7)) << 4)) = kreg[i];
-            // V^T: row = d, position of `key` inside its 16-key group permuted to [0-3, 8-11, 4-7, 12-15] so that the 8
-            // keys one lane-half contributes to an MFMA k-step are one contiguous 16-byte piece
-            const int k16 = key & 15;
-            const int pos = (key & ~15) | (k16 & 3) | ((k16 & 8) >> 1) | ((k16 & 4) << 1);
-            const half8 v = __builtin_bit_cast(half8, vreg[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = pc * 8 + e;
-                *reinterpret_cast<_Float16*>(Vt + d * 128 + (((pos >> 3) ^ ((d >> 1) & 7)) << 4) + (pos & 7) * 2) = v[e];
-            }
+        stage1(0, k0, v0);
+        stage1(1, k1, v1);
+        if constexpr (PPT > 2) {
+            stage1(2, k2, v2);
+            stage1(3, k3, v3);
         }
     };
 
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __r
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx * scale_log2);
-        const float alpha = exp2f(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float psum = 0.f;
         half8 pf[2][2];                           // [key tile j][k-step t]: 8 fp16 probabilities = the B operand
 #pragma unroll
@@ -120,7 +132,9 @@ __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __r
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const _Float16 ph = (_Float16)exp2f(s[j][t * 8 + e] * scale_log2 - m_new);
+                    // raw v_exp_f32 (libm's exp2f wraps it in 5 more instructions for results below 2^-126, which round to 0 in
+                    // fp16 anyway): a third of this kernel's vector-ALU work
+                    const _Float16 ph = (_Float16)__builtin_amdgcn_exp2f(s[j][t * 8 + e] * scale_log2 - m_new);
                     pf[j][t][e] = ph;
                     psum += (float)ph;            // the sum of what is actually multiplied into V (like the reference)
                 }
