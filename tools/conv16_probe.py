@@ -1,6 +1,10 @@
 #!/usr/bin/env python
-"""Development probe: ablation builds of conv16.hip (WRONG results on purpose) over a K sweep, to separate the
-per-launch fixed cost (dispatch, prologue, epilogue) from the main-loop rate."""
+"""Development probe: several builds of conv16.hip side by side in ONE session (box-to-box variation is 2-4 %), over the
+ADM layer shapes.  Ablation builds (-DDDNM_P16_NO_*) give WRONG results on purpose and separate the per-launch fixed cost
+(dispatch, prologue, epilogue) from the main-loop rate; "old" is a library built beforehand from another source
+(tools/_build/libp16_old.so).  Environment: ONLY=a,b (variants), SHAPES=low|one|mid (shape lists), GN=1 (fused GroupNorm),
+COLD=1 (rotate through > 512 MB of weight copies: weights come from HBM as inside a forward -- without it the low-resolution
+layers look 15-20 % faster than they are and a deeper weight pipeline shows no gain)."""
 import ctypes
 import os
 import subprocess
@@ -18,7 +22,7 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_nowl": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_WLOAD"], "ne_nosync": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_SYNC"],
             "ne_nofrag": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG"],
             "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
-            "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None, "nwb3": None, "maxm0": ["-DDDNM_P16_WMAJOR_MAXM=0"], "maxm16": ["-DDDNM_P16_WMAJOR_MAXM=16"],
+            "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None, "maxm0": ["-DDDNM_P16_WMAJOR_MAXM=0"], "maxm16": ["-DDDNM_P16_WMAJOR_MAXM=16"],
             "maxm64": ["-DDDNM_P16_WMAJOR_MAXM=64"],
             "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
 if os.environ.get("ONLY"):
@@ -52,12 +56,14 @@ print("shape                 " + " ".join(f"{n:>10s}" for n in libs) + "   (us)"
 LOW = [("warm", 256, 256, 256, 3, 1), ("512->512@64 res", 512, 512, 64, 3, 1), ("512->1024@32", 512, 1024, 32, 3, 0),
        ("1024->1024@32 res", 1024, 1024, 32, 3, 1), ("1024->1024@16 res", 1024, 1024, 16, 3, 1),
        ("2048->1024@16", 2048, 1024, 16, 3, 0), ("1536->1024@32", 1536, 1024, 32, 3, 0)]
+MID = [("warm", 256, 256, 256, 3, 1), ("256->256@128 res", 256, 256, 128, 3, 1), ("256->256@128", 256, 256, 128, 3, 0),
+       ("512->256@128", 512, 256, 128, 3, 0), ("768->256@128", 768, 256, 128, 3, 0), ("256->512@128", 256, 512, 128, 3, 0)]
 ONE = [("warm", 256, 256, 256, 3, 1),
        ("9216->1024@8 1x1", 9216, 1024, 8, 1, 0), ("1024->3072@32 1x1", 1024, 3072, 32, 1, 0),
        ("1024->1024@16 1x1", 1024, 1024, 16, 1, 0), ("1024->3072@16 1x1", 1024, 3072, 16, 1, 0),
        ("1024->1024@8 1x1", 1024, 1024, 8, 1, 0), ("1024->3072@8 1x1", 1024, 3072, 8, 1, 0),
        ("512->1536@32 1x1", 512, 1536, 32, 1, 0), ("512->512@32 1x1", 512, 512, 32, 1, 0)]
-for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE}.get(os.environ.get("SHAPES"), None) or [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
+for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE, "mid": MID}.get(os.environ.get("SHAPES"), None) or [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
                                    ("256->256@256 res", 256, 256, 256, 3, 1), ("256->256@256", 256, 256, 256, 3, 0),
                                    ("512->256@256", 512, 256, 256, 3, 0), ("1024->256@256", 1024, 256, 256, 3, 0),
                                    ("256->256@128 res", 256, 256, 128, 3, 1), ("512->512@128 res", 512, 512, 128, 3, 1),
