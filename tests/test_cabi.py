@@ -107,3 +107,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.DDNMHipError):
         _lib.lib()
+
+
+def test_conv16_plans_without_a_gpu(lib):
+    """The planning entry points are host code: which launches the fp16 convolution accepts, whether they slice K
+    (workspace) and how many GroupNorm partial tiles they emit -- the ADM layer shapes of BASELINE configs 3-5."""
+    from ddnm_amd._lib import Conv16Desc
+
+    def plan(B, H, Cin, Cout, k, **kw):
+        d = Conv16Desc()
+        d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, H, Cin, Cout, k
+        for key, v in kw.items():
+            setattr(d, key, v)
+        ok = lib.ddnm_conv16_supported(ctypes.byref(d)) == 1
+        return ok, (lib.ddnm_conv16_workspace_floats(ctypes.byref(d)) if ok else None), \
+            (lib.ddnm_conv16_stats_tiles(ctypes.byref(d)) if ok else None)
+
+    assert plan(4, 256, 256, 256, 3) == (True, 0, 256)              # 1024 tiles of 256 pixels, no slicing
+    assert plan(4, 64, 512, 512, 3) == (True, 0, 32)                # 256 tiles of 128 pixels
+    ok, ws, tiles = plan(4, 16, 1024, 1024, 3)                      # 32 tiles -> 8 slices of fp32 slabs
+    assert ok and ws == 8 * 4 * 16 * 16 * 1024 and tiles > 0
+    assert plan(4, 16, 1024, 1024, 1) == (True, 0, 2)               # 1x1 with K <= 1024: never sliced
+    ok, ws, _ = plan(4, 8, 9216, 1024, 1)                           # the im2col'ed 8x8 level: K = 9216 is sliced
+    assert ok and ws > 0
+    assert plan(4, 8, 1024, 1024, 3)[0] is False                    # 8x8 images have no 3x3 pixel tile (im2col route)
+    assert plan(4, 256, 256, 6, 3, out_nchw_f32=1)[:2] == (True, 0)    # the fp32 NCHW output convolution
+    assert plan(4, 256, 200, 256, 3)[0] is False                    # Cin must be a multiple of 64
