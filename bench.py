@@ -58,13 +58,15 @@ def make_config():
         sampling=ns(batch_size=BATCH_PER_GPU))
 
 
-def cpu_baseline(cfg, sd, budget_s=25.0):
-    """Reported baseline (not the optimisation target): the oracle restatement of the reference path
-    (bit-identical to the reference UNet on CPU, tests/test_oracle_pins.py) on this box's host cores.
-    Bounded sample: B=1, as many reverse steps of the 100 as fit in `budget_s`, extrapolated; then the workload's own
-    batch (B=8) for 3 reverse steps, reported next to it (`b8_value`).  The intra-op thread count is calibrated
-    first on a reduced UNet (oversubscribing a many-core host makes the ATen CPU kernels dramatically slower)."""
-    from oracle import cases, sampler, unet_celeba
+def cpu_baseline(cfg, sd, budget_s=90.0):
+    """Reported baseline (not the optimisation target): the reference path on this box's host cores -- the reference's
+    own `Model` when /root/reference is importable (`kind: "reference"`, build container only), otherwise the oracle
+    restatement (`kind: "port"`; bit-identical to the reference UNet on CPU, tests/test_oracle_pins.py).
+    Bounded sample: B=1, as many reverse steps of the 100 as fit in `budget_s` (at least 30, all 100 when they fit),
+    extrapolated; then the workload's own batch (B=8) for 3 reverse steps (`b8_value`, the like-for-like figure).  The
+    intra-op thread count is calibrated first on a reduced UNet (oversubscribing a many-core host makes the ATen CPU
+    kernels dramatically slower)."""
+    from oracle import cases, ref_import, sampler, unet_celeba
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -86,7 +88,16 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
             best = (nt, dt)
     threads = best[0] or min(avail, 8)
     torch.set_num_threads(threads)
+    kind = "port"
     net = unet_celeba.Net(sd, cfg)
+    if ref_import.available():
+        try:
+            ref = ref_import.load().models.Model(cfg)
+            ref.load_state_dict(sd)
+            ref.eval()
+            net, kind = (lambda x, t, ref=ref: ref(x, t)), "reference"
+        except Exception:      # noqa: BLE001
+            kind = "port"
     op = cases.make_operator("sr_bicubic", 256)
 
     class Stop(Exception):
@@ -109,9 +120,9 @@ def cpu_baseline(cfg, sd, budget_s=25.0):
     t0 = time.perf_counter()
     net(torch.zeros(1, 3, 256, 256), torch.tensor([990.0]))          # warm-up forward, also sizes the sample
     t_fwd = time.perf_counter() - t0
-    n_steps = int(max(1, min(10, (budget_s * 0.6) // max(t_fwd, 1e-3))))
+    n_steps = int(max(30, min(T_SAMPLING, budget_s // max(t_fwd, 1e-3))))
     dt = timed(1, n_steps)
-    out = {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": threads, "kind": "port",
+    out = {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": threads, "kind": kind,
            "sample": f"B=1, {n_steps} of {T_SAMPLING} reverse steps timed ({dt:.1f} s) on {threads} threads ({avail} "
                      f"logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}; `b8_value`: the workload's own batch "
                      "of 8 for 3 reverse steps, same extrapolation"}
@@ -140,7 +151,16 @@ ADM_WORKLOADS = {
 }
 
 
-def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roofline=True):
+def real_inpainting_mask():
+    """The reference's exp/inp_masks/mask.npy (256 x 256, 1 = kept), committed bit-packed as tests/golden/inp_mask.npz."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "inp_mask.npz"))
+    shape = tuple(g["shape"])
+    bits = np.unpackbits(g["packed"])[: shape[0] * shape[1]]
+    return torch.from_numpy(bits.reshape(shape).astype(np.int64))
+
+
+def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roofline=True, lib_digest=None):
     """One ImageNet workload: ADM UNet (552.81 M parameters, 2242.87 GFLOP per forward per image) in the runner's
     `use_fp16: true` mode = fp16 activations + fp16 MFMA operands, fp32 accumulation (ddnm_amd/guided_diffusion/unet.py).
     weak scaling (default): every rank restores the per-GPU shard of the BASELINE config; `strong`: the config's GLOBAL
@@ -190,7 +210,7 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
     elif name == "c5":
         op = WalshHadamardCS(3, 256, 4, torch.randperm(256 * 256, generator=g), dev)
     else:
-        mask = (torch.rand(256, 256, generator=g) > 0.26).long().reshape(-1)        # 74 % kept, like exp/inp_masks/mask.npy
+        mask = real_inpainting_mask().reshape(-1)        # exp/inp_masks/mask.npy of the reference (bit-packed copy)
         r = torch.nonzero(mask == 0).long().reshape(-1) * 3
         op = Inpainting(3, 256, torch.cat([r, r + 1, r + 2], 0), dev)
     y = op.A(x_orig)
@@ -211,16 +231,14 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
         out = one_pass()
     torch.cuda.synchronize()
     ddist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = tmax.item()
+    dt_rank = time.perf_counter() - t0
+    dt, dt_min = ddist.reduce_scalar(dt_rank, dev, "max"), ddist.reduce_scalar(dt_rank, dev, "min")
     value = steps * n_total / dt
     per_step = ADM_CC_FLOPS_PER_STEP if name == "c5" else ADM_FLOPS_PER_FWD
     tfl = value * nfe * per_step / 1e12 / world
     res = {"value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(dt / steps * 1e3, 2), "scaling": "strong" if strong else "weak",
+           "ms_per_step": round(dt / steps * 1e3, 2), "ms_per_step_rank_min": round(dt_min / steps * 1e3, 2),
+           "scaling": "strong" if strong else "weak",
            "dtype": "f16 (activations and MFMA operands; f32 accumulate, GroupNorm statistics, softmax)",
            "data": "synthetic",
            "config": {"workload": W["desc"], "global_batch": n_total, "per_gpu_batch": B, "nfe_per_image": nfe},
@@ -240,8 +258,23 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
             kname, r = max(summ.items(), key=lambda kv: kv[1]["ms"])
             total_ms = sum(v["ms"] for v in summ.values())
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            # HBM traffic / MFMA-busy / rocprofv3 launch time of the same kernels from the PMC passes over an ADM forward
+            # at B=4 (tools/adm_fwd.py), bound to the loaded binary by its source digest like the c2 figures
+            traffic = mfma_busy = frac_rocprof = None
+            pmc_note = "no profiles/*_adm_pmc_conv16.json carries the loaded library's source digest"
+            hit = pmc_for_loaded_binary(lib_digest, "_adm_pmc_conv16.json") if lib_digest else None
+            if hit is not None and B == 4:
+                fname, pj = hit
+                traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_busy_frac_weighted")
+                if pj.get("rocprof_avg_launch_us"):
+                    frac_rocprof = round(r["flops"] / r["launches"] / (pj["rocprof_avg_launch_us"] * 1e-6) / 1e12
+                                         / PEAK_F16_TFLOPS, 4)
+                pmc_note = f"profiles/{fname}: PMC passes over 2 ADM forwards at B=4 ({pj.get('kernel')}), same source digest"
+            elif hit is not None:
+                pmc_note = f"profiles/{hit[0]} was collected at B=4; this workload runs B={B}"
             res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                               "mfma_busy_pmc": mfma_busy, "frac_rocprof": frac_rocprof, "traffic_note": pmc_note,
                                "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                                "avg_flops_per_launch": r["flops"] / r["launches"],
                                "share_of_conv_time": round(r["ms"] / total_ms, 4),
@@ -254,14 +287,14 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
     return res
 
 
-def pmc_for_loaded_binary(lib_digest):
+def pmc_for_loaded_binary(lib_digest, suffix="_pmc_dominant_kernel.json"):
     """HBM traffic / MFMA-busy of the dominant kernel come from separate rocprofv3 --pmc passes (bench.py cannot run
     under the profiler itself); tools/pmc_summary.py stamps them with the digest of the sources the profiled binary was
     built from.  They are reported ONLY when that digest is the loaded library's -- a kernel edit invalidates them."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
-        if f.endswith("_pmc_dominant_kernel.json"):
+        if f.endswith(suffix):
             try:
                 pj = json.load(open(os.path.join(pdir, f)))
             except Exception:      # noqa: BLE001
@@ -269,6 +302,26 @@ def pmc_for_loaded_binary(lib_digest):
             if pj.get("source_digest") == lib_digest:
                 best = (f, pj)
     return best
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: re-exec under torch.distributed.run, one rank per GPU (the reference
+    takes every visible GPU from one plain command through nn.DataParallel, guided_diffusion/diffusion.py:140,164,180).
+    Fails loudly when fewer than N devices are visible -- unless DDNM_DIST_BACKEND=gloo, the 1-GPU test mode in which
+    the ranks share one device."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("DDNM_DIST_BACKEND") != "gloo":
+        sys.stderr.write(f"[bench] --gpus {args.gpus} but only {ndev} GPU(s) are visible: refusing to measure fewer "
+                         f"devices than asked for\n")
+        sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -296,20 +349,29 @@ def main():
     from ddnm_amd.guided_diffusion.diffusion import get_beta_schedule
     from ddnm_amd.guided_diffusion.models import Model
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                         # does not return
     rank, local_rank, world = ddist.init()
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE\n")
+    if world > torch.cuda.device_count() and ddist.backend_name() != "gloo":
+        sys.stderr.write(f"[bench] {world} ranks but {torch.cuda.device_count()} visible GPU(s)\n")
+        sys.exit(2)
     dev = torch.device("cuda", torch.cuda.current_device())
     lib_digest = _lib.lib().ddnm_build_digest().decode()
+    ranks_seen = int(round(ddist.reduce_scalar(1.0, dev, "sum")))        # an all_reduce of ones over the real group
+    dist_info = {"backend": {"nccl": "nccl (RCCL)"}.get(ddist.backend_name(), ddist.backend_name()),
+                 "ranks_seen": ranks_seen}
 
     cfg = make_config()
     if args.workload != "c2":
         res = adm_workload(args.workload, ddist, rank, world, dev, args.steps, args.warmup,
-                           strong=(args.scaling == "strong"), roofline=not args.no_roofline)
+                           strong=(args.scaling == "strong"), roofline=not args.no_roofline, lib_digest=lib_digest)
         line = {"metric": "restored images/sec @256x256, 100 DDIM steps", "higher_is_better": True, "vs_baseline": None,
                 "library_digest": lib_digest[:16]}
         line.update(res)
+        line.update(dist_info)
         if rank == 0:
             print(json.dumps(line), flush=True)
         if world > 1:
@@ -342,11 +404,8 @@ def main():
         out = one_pass()
     torch.cuda.synchronize()
     ddist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = tmax.item()
+    dt_rank = time.perf_counter() - t0
+    dt, dt_min = ddist.reduce_scalar(dt_rank, dev, "max"), ddist.reduce_scalar(dt_rank, dev, "min")
     assert out.shape[0] == B * world and bool(torch.isfinite(out).all())
     # data-consistency spot check of the last pass (this rank's slice): A x_0 = y
     mine = out[rank * B:(rank + 1) * B]
@@ -356,7 +415,8 @@ def main():
     line = {
         "metric": baseline_metric(), "value": round(value, 4),
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "ms_per_step_rank_min": round(dt_min / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "backend": dist_info["backend"], "ranks_seen": ranks_seen,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "celeba_hq.yml SVD sr_bicubic 4x, sigma_y=0, eta=0.85, T_sampling=100, "
                                "batch_size=8 per GPU (BASELINE configs[1])",
@@ -417,14 +477,21 @@ def main():
             line["roofline"] = {"error": repr(e)}
     if world > 1:
         ddist.barrier()
-    if world == 1 and not args.no_extra_workloads:
-        # BASELINE configs[2..4] on this GPU (their per-GPU shards), short: 1 warm-up + 2 timed restorations each
+    if not args.no_extra_workloads:
         del model
         torch.cuda.empty_cache()
         line["workloads"] = {}
-        for wname in ("c3", "c4", "c5"):
-            try:
-                line["workloads"][wname] = adm_workload(wname, ddist, rank, world, dev, 2, 1, roofline=not args.no_roofline)
+        if world == 1:
+            # BASELINE configs[2..4] on this GPU (their per-GPU shards), short: 1 warm-up + 2 timed restorations each
+            plan = [("c3", False, 2), ("c4", False, 2), ("c5", False, 2)]
+        else:
+            # N > 1: configs[2] / configs[3] with their fixed GLOBAL batch (32 / 16) split over the ranks present
+            # (strong scaling: the driver's per-N lines give the curve), 1 warm-up + 1 timed restoration each
+            plan = [("c3", True, 1), ("c4", True, 1)]
+        for wname, strong, nsteps in plan:
+            try:                       # every rank takes part (collectives inside); a failure must not cost the line
+                line["workloads"][wname] = adm_workload(wname, ddist, rank, world, dev, nsteps, 1, strong=strong,
+                                                        roofline=not args.no_roofline, lib_digest=lib_digest)
             except Exception as e:    # noqa: BLE001
                 line["workloads"][wname] = {"error": repr(e)}
     if rank == 0:

@@ -767,6 +767,21 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
             (d->SC1 > 0 && !d->skip1))
             return DDNM_E_SHAPE;
     }
+    {   // The kernel addresses every tensor through 32-bit byte offsets of a raw buffer descriptor and fetches zero
+        // padding through the out-of-range offset 0x80000000: every operand must stay below 2 GiB (split the batch on
+        // the host beyond that) -- otherwise the padding offset would land inside the buffer and read real data.
+        const int64_t lim = (int64_t)1 << 31;
+        const int64_t src_pix = (int64_t)d->B * (d->ups ? d->H / 2 : d->H) * (d->ups ? d->W / 2 : d->W);
+        const int64_t out_pix = (int64_t)d->B * d->H * d->W;
+        const int64_t c0 = d->src1 ? d->C0 : d->Cin, c1 = d->Cin - c0;
+        const int64_t cmax = c0 > c1 ? c0 : c1;
+        const int64_t scmax = d->SC0 > d->SC1 ? d->SC0 : d->SC1;
+        if (src_pix * cmax * 2 >= lim || out_pix * d->Cout * (d->out_nchw_f32 ? 4 : 2) >= lim ||
+            out_pix * scmax * 2 >= lim ||
+            (int64_t)pl.n_tiles * (pl.small ? 32 : C16_BN) * pl.taps * d->Cin * 2 >= lim ||
+            (int64_t)pl.n_tiles * C16_BN * (d->SC0 + d->SC1) * 2 >= lim)
+            return DDNM_E_SHAPE;
+    }
     if (d->stats_out && pl.stats_tiles <= 0) return DDNM_E_SHAPE;
     if ((d->gn_scale == nullptr) != (d->gn_shift == nullptr)) return DDNM_E_BADARG;
     if (d->gn_scale && pl.taps != 9) return DDNM_E_SHAPE;          // 1x1 launches take an already activated operand

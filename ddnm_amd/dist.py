@@ -74,14 +74,33 @@ def gather_images(x_local, n_total=None):
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
 
 
-def reduce_sum(value, device):
-    """Scalar sum over ranks (PSNR accumulation, diffusion.py:602)."""
+def reduce_scalar(value, device, op="sum"):
+    """Scalar sum / max / min over ranks (gloo reduces host tensors, RCCL device tensors)."""
     if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "gloo":
         device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
     return t.item()
+
+
+def reduce_sum(value, device):
+    """Scalar sum over ranks (PSNR accumulation, diffusion.py:602)."""
+    return reduce_scalar(value, device, "sum")
+
+
+def world_state():
+    """(rank, world) of the INITIALISED process group, (0, 1) without one.  A process started under torchrun that never
+    called init() must not shard: gather_images / reduce_sum would silently keep its slice only."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    if int(os.environ.get("WORLD_SIZE", 1)) > 1:
+        raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call ddnm_amd.dist.init() first")
+    return 0, 1
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else "none"
 
 
 def barrier():
@@ -90,3 +109,18 @@ def barrier():
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
             dist.barrier()
+
+
+def broadcast_flag(flag):
+    """Rank 0's boolean, on every rank (a collective: also orders rank 0's side effects before the others go on)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.broadcast(t, src=0)
+    return bool(t.item())
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

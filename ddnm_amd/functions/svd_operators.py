@@ -112,6 +112,9 @@ def _gather(vec, idx, n_out, scale=None):
 
 
 def _site_matmul(vec, M, sites, n, sb, ss, sj, trans):
+    if n > 16:      # ddnm_site_matmul_f32 keeps one n x n site matrix in registers (n <= 16: ratio <= 4, colour = 3)
+        raise NotImplementedError(f"matrix-free V / Vt / At / A_pinv_eta with {n} entries per site (sr_averagepooling "
+                                  "with deg_scale > 4): only the direct A / A_pinv forms the sampler uses are built")
     v = _flat(vec)
     out = torch.empty_like(v)
     check(_lib.lib().ddnm_site_matmul_f32(_p(v), _p(M), _p(out), v.shape[0], sites, n, sb, ss, sj, int(trans),
@@ -120,8 +123,8 @@ def _site_matmul(vec, M, sites, n, sb, ss, sj, trans):
 
 
 def _pad_scale(f, n):
-    """Per-entry factors over the big (V) dimension: `f` on the first len(f) entries (zeros beyond are never read as the
-    gather writes 0 there)."""
+    """Per-entry factors over the big (V) dimension: `f` on the first len(f) entries, ONES beyond (those entries of the
+    gathered vector are zero already, so their factor is never seen)."""
     out = torch.ones(n, dtype=torch.float32, device=f.device)
     out[: f.numel()] = f
     return out.contiguous()

@@ -358,7 +358,7 @@ class Diffusion(object):
         A_funcs = build_operator(args.deg, args.deg_scale, config, self.device)
         args.sigma_y = 2 * args.sigma_y          # scaling to [-1, 1] (:524)
         sigma_y = args.sigma_y
-        rank, _, world = ddist.env_world()
+        rank, world = ddist.world_state()      # the INITIALISED group (env-only sharding without a group loses shards)
         print(f"Start from {args.subset_start}")
         idx_so_far = args.subset_start
         psnr_sum, n_done = 0.0, 0
@@ -441,7 +441,7 @@ class Diffusion(object):
         op = self._simplified_operator()
         args.sigma_y = 2 * args.sigma_y
         sigma_y = args.sigma_y
-        rank, _, world = ddist.env_world()
+        rank, world = ddist.world_state()      # the INITIALISED group (env-only sharding without a group loses shards)
         print(f"Start from {args.subset_start}")
         idx_so_far = args.subset_start
         psnr_sum, n_done = 0.0, 0

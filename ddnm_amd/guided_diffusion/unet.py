@@ -144,7 +144,6 @@ class UNetModel:
         softmax, embeddings, `out.*` stay fp32 exactly like fp16_util.py:15-22 leaves them."""
         self.use_fp16 = True
         if self.w is not None:
-            self._pack_f16()
             self._pack_h16()
         return self
 
@@ -152,13 +151,23 @@ class UNetModel:
         self.use_fp16 = False
         return self
 
+    def _dev(self, raw):
+        return raw.to(device=self.device, dtype=torch.float32).contiguous()
+
     def _pack_f16(self):
+        """fp16-operand packs of the first-generation path (DDNM_ADM_GEN1=1): built on first use only -- the raw
+        weights stay on the HOST (`_raw_all`), so the default fp16-activation path keeps one packed copy per weight in
+        HBM (raw fp32 + fp32 packs + both fp16 packs were ~4x the weight footprint)."""
+        if "f16.ready" in self.w:
+            return
         for key in self._f16_keys:
-            if key + ".f16" not in self.w:
-                self.w[key + ".f16"] = ops.pack_conv_weight_f16(self._raw[key])
-        for key, raw in self._raw.items():
-            if key.endswith(".pad64") and key + ".f16" not in self.w:
-                self.w[key + ".f16"] = ops.pack_conv_weight_f16(raw, cin_pad=CIN_PAD_F16)
+            self.w[key + ".f16"] = ops.pack_conv_weight_f16(self._dev(self._raw_all[key]))
+            if key.endswith(".skip_connection.weight"):
+                self.w[key[:-len(".weight")] + ".fused.f16"] = ops.pack_skip_weight(self._dev(self._raw_all[key]), f16=True)
+        if self._pad64_key is not None:
+            self.w[self._pad64_key + ".pad64.f16"] = ops.pack_conv_weight_f16(self._dev(self._raw_all[self._pad64_key]),
+                                                                             cin_pad=CIN_PAD_F16)
+        self.w["f16.ready"] = True
 
     def _pack_h16(self):
         """fp16 (O,ky,kx,I) weights of the fp16-activation path, Cout padded to 256 rows (ops.pack_conv_weight16)."""
@@ -166,6 +175,7 @@ class UNetModel:
         if "h16.ready" in w:
             return
         for key, raw in self._raw_all.items():
+            raw = self._dev(raw)
             if key.endswith("input_blocks.0.0.weight"):
                 w[key + ".h16"] = ops.pack_conv_weight16(raw, cin_pad=CIN_PAD_F16)
             elif key.endswith(".skip_connection.weight"):
@@ -228,8 +238,9 @@ class UNetModel:
         dev = self.device
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731 (fp16 ckpts upcast)
         w = {}
-        self._raw, self._f16_keys = {}, []
-        self._raw_all = {}
+        self._f16_keys, self._pad64_key = [], None
+        self._raw_all = {}             # HOST references to the checkpoint's conv weights (packed on demand)
+        host = lambda k: sd[k].detach()   # noqa: E731
         for k in ("time_embed.0", "time_embed.2"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
         if self.num_classes is not None:
@@ -241,9 +252,9 @@ class UNetModel:
                 if L[0] == "conv":
                     w[n + ".weight"] = ops.pack_conv_weight(g(n + ".weight"), cin_pad=CIN_PAD)
                     w[n + ".bias"] = g(n + ".bias")
-                    self._raw_all[n + ".weight"] = g(n + ".weight")
+                    self._raw_all[n + ".weight"] = host(n + ".weight")
                     if L[2] % 128 == 0:          # fp16 mode: the 3 input channels are zero-padded to one 64-channel chunk
-                        self._raw[n + ".weight.pad64"] = g(n + ".weight")
+                        self._pad64_key = n + ".weight"
                 elif L[0] == "res":
                     for norm in ("in_layers.0", "out_layers.0"):
                         w[f"{n}.{norm}.weight"], w[f"{n}.{norm}.bias"] = g(f"{n}.{norm}.weight"), g(f"{n}.{norm}.bias")
@@ -251,39 +262,35 @@ class UNetModel:
                         raw = g(f"{n}.{conv}.weight")
                         w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
                         w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
-                        self._raw_all[f"{n}.{conv}.weight"] = raw
+                        self._raw_all[f"{n}.{conv}.weight"] = host(f"{n}.{conv}.weight")
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
-                            self._raw[f"{n}.{conv}.weight"] = raw
                             self._f16_keys.append(f"{n}.{conv}.weight")
                     fw.append(g(n + ".emb_layers.1.weight"))
                     fb.append(g(n + ".emb_layers.1.bias"))
                     if L[1] != L[2]:
                         raw = g(n + ".skip_connection.weight")
-                        self._raw_all[n + ".skip_connection.weight"] = raw
+                        self._raw_all[n + ".skip_connection.weight"] = host(n + ".skip_connection.weight")
                         w[n + ".skip_connection.weight"] = ops.pack_conv_weight(raw)
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
-                            self._raw[n + ".skip_connection.weight"] = raw
                             self._f16_keys.append(n + ".skip_connection.weight")
                         w[n + ".skip_connection.bias"] = g(n + ".skip_connection.bias")
                         w[n + ".skip_connection.fused"] = ops.pack_skip_weight(raw)
-                        w[n + ".skip_connection.fused.f16"] = ops.pack_skip_weight(raw, f16=True)
                         w[n + ".out_plus_skip.bias"] = (g(n + ".out_layers.3.bias") + g(n + ".skip_connection.bias")).contiguous()
                 else:
                     w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
                     for conv in ("qkv", "proj_out"):                     # Conv1d(k=1) == 1x1 convolution
                         raw = g(f"{n}.{conv}.weight").unsqueeze(-1)
-                        self._raw_all[f"{n}.{conv}.weight"] = raw
+                        self._raw_all[f"{n}.{conv}.weight"] = host(f"{n}.{conv}.weight").unsqueeze(-1)
                         w[f"{n}.{conv}.weight"] = ops.pack_conv_weight(raw)
                         w[f"{n}.{conv}.bias"] = g(f"{n}.{conv}.bias")
                         if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
-                            self._raw[f"{n}.{conv}.weight"] = raw
                             self._f16_keys.append(f"{n}.{conv}.weight")
         w["film_cat.weight"] = torch.cat(fw, 0).contiguous()
         w["film_cat.bias"] = torch.cat(fb, 0).contiguous()
         w["out.0.weight"], w["out.0.bias"] = g("out.0.weight"), g("out.0.bias")
         w["out.2.weight"] = ops.pack_conv_weight(g("out.2.weight"))
         w["out.2.bias"] = g("out.2.bias")
-        self._raw_all["out.2.weight"] = g("out.2.weight")
+        self._raw_all["out.2.weight"] = host("out.2.weight")
         half = self.model_channels // 2
         w["time.freq"] = torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
         self.w = w
@@ -292,7 +299,6 @@ class UNetModel:
         if self._graphs is not None:
             self._graphs.reset()
         if self.use_fp16:
-            self._pack_f16()
             self._pack_h16()
         return self
 
@@ -349,7 +355,7 @@ class UNetModel:
                     return ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
                                       bias=w[n + ".out_plus_skip.bias"], skip=(x0, x1),
                                       skip_weight=w[n + ".skip_connection.fused"],
-                                      skip_weight_f16=w[n + ".skip_connection.fused.f16"], emit_stats=True,
+                                      skip_weight_f16=w.get(n + ".skip_connection.fused.f16"), emit_stats=True,
                                       weight_f16=self._w16(n + ".out_layers.3.weight"))
                 xs = ops.conv2d(x0, w[n + ".skip_connection.weight"], cout, 1, src1=x1,
                                 bias=w[n + ".skip_connection.bias"], weight_f16=self._w16(n + ".skip_connection.weight"))
@@ -522,6 +528,8 @@ class UNetModel:
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
         if self.use_fp16 and os.environ.get("DDNM_ADM_GEN1") != "1":
             return self._forward16(x, film_all)
+        if self.use_fp16:
+            self._pack_f16()            # first-generation path: its fp16-operand packs are built on first use
 
         n0 = "input_blocks.0.0"
         H, W = x.shape[2], x.shape[3]

@@ -76,25 +76,10 @@ def parse_args_and_config(argv=None):
     root.addHandler(handler)
     root.setLevel(level)
 
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    os.makedirs(os.path.join(args.exp, "image_samples"), exist_ok=True)
     args.image_folder = os.path.join(args.exp, "image_samples", args.image_folder)
-    if os.path.exists(args.image_folder) and not args.ni and world > 1:
-        # the other ranks cannot see rank 0's answer before the process group exists: refuse on EVERY rank instead of
-        # letting rank 0 exit while the others wait in the first barrier
-        print("Output image folder exists; pass --ni to overwrite it in a multi-process run. Program halted.")
-        sys.exit(0)
-    if rank == 0:
-        if os.path.exists(args.image_folder):
-            overwrite = args.ni
-            if not overwrite:
-                answer = input(f"Image folder {args.image_folder} already exists. Overwrite? (Y/N)")
-                overwrite = answer.upper() == "Y"
-            if not overwrite:
-                print("Output image folder exists. Program halted.")
-                sys.exit(0)
-            shutil.rmtree(args.image_folder)
-        os.makedirs(args.image_folder)
+    if int(os.environ.get("WORLD_SIZE", 1)) == 1:        # single process: here, like the reference (main.py:112-135)
+        if not prepare_image_folder(args, 0):
+            sys.exit(0)
 
     device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
     logging.info("Using device: {}".format(device))
@@ -107,13 +92,41 @@ def parse_args_and_config(argv=None):
     return args, config
 
 
+def prepare_image_folder(args, rank):
+    """The reference's overwrite protocol (main.py:112-135), decided by rank 0 ALONE: the other ranks of a
+    multi-process run never look at the folder (a rank that arrived after rank 0's makedirs used to see the fresh
+    folder, print "Program halted" and leave rank 0 waiting in the first barrier) -- they learn the verdict through
+    `ddist.broadcast_flag` once the process group exists.  Returns False when the run must stop."""
+    if rank != 0:
+        return True
+    os.makedirs(os.path.join(args.exp, "image_samples"), exist_ok=True)
+    if os.path.exists(args.image_folder):
+        overwrite = args.ni
+        if not overwrite and int(os.environ.get("WORLD_SIZE", 1)) > 1:
+            print("Output image folder exists; pass --ni to overwrite it in a multi-process run. Program halted.")
+            return False
+        if not overwrite:
+            answer = input(f"Image folder {args.image_folder} already exists. Overwrite? (Y/N)")
+            overwrite = answer.upper() == "Y"
+        if not overwrite:
+            print("Output image folder exists. Program halted.")
+            return False
+        shutil.rmtree(args.image_folder)
+    os.makedirs(args.image_folder)
+    return True
+
+
 def main(argv=None):
     args, config = parse_args_and_config(argv)
     try:
         from ddnm_amd import dist as ddist
         from ddnm_amd.guided_diffusion.diffusion import Diffusion
-        ddist.init()
-        ddist.barrier()          # rank 0 has (re)created the image folder
+        rank, _, world = ddist.init()
+        if world > 1:
+            # rank 0's verdict on the output folder; the broadcast is also the "folder exists" barrier
+            if not ddist.broadcast_flag(prepare_image_folder(args, rank)):
+                ddist.shutdown()
+                return 0
         runner = Diffusion(args, config)
         runner.sample(args.simplified)
     except Exception:

@@ -138,6 +138,9 @@ FULL_CASES = {
     "c3": dict(net="adm", deg="colorization", batch=1, T=100, travel=(1, 1), class_cond=False, record=(10, 50, 90)),
     "c4": dict(net="adm", deg="inpainting", batch=1, T=100, travel=(10, 3), class_cond=False, record=(9, 229, 449)),
     "c5": dict(net="adm", deg="cs_walshhadamard", batch=1, T=100, travel=(1, 1), class_cond=True, record=(10, 50, 90)),
+    # configs[2] at the per-GPU batch bench.py times (B = 4 selects other conv16 launch plans than B = 1), 10 of the
+    # 100 steps: ~40 evaluations of the full net through the reference on CPU
+    "c3b4": dict(net="adm", deg="colorization", batch=4, T=10, travel=(1, 1), class_cond=False, record=(1, 5, 8)),
 }
 
 

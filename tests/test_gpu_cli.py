@@ -166,3 +166,27 @@ def test_two_ranks_shard_every_batch_and_match_one_rank(hip, tmp_path):
         # equal shapes run bit-identical kernels; batch-size dependent split-K plans may move a value by 1e-6, i.e. at
         # most an isolated 8-bit rounding flip
         assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3, n
+
+
+def test_bench_self_launches_ranks_from_a_plain_command(hip):
+    """`python bench.py --gpus 2` with no torchrun around it re-executes itself under torch.distributed.run (the
+    reference scales from one plain command too: nn.DataParallel, guided_diffusion/diffusion.py:140,164,180).  On this
+    1-GPU lease the two ranks share the device through the gloo backend: the printed line must say so -- n_gpus 2,
+    ranks_seen 2 (an all_reduce of ones), both ranks' step times.  No scaling number can be measured here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DDNM_DIST_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extra-workloads", "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert 0 < line["ms_per_step_rank_min"] <= line["ms_per_step"]
+    assert line["value"] > 0 and line["consistency_max_abs"] < 1e-3

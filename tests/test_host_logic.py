@@ -178,3 +178,17 @@ def test_respaced_betas_keep_only_integer_timesteps():
     betas = np.linspace(1e-4, 0.02, 1000)
     new, keep = respaced_betas(betas, {0.0, 10.0, 10.5, 10.9, 20.0, 999.0})
     assert keep == [0, 10, 20, 999] and np.all(new > 0)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` where fewer devices exist must fail loudly (exit 2), never measure one GPU and print
+    a line (a directly invoked scaling command produced an n_gpus = 1 line)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DDNM_DIST_BACKEND")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "refusing to measure fewer" in r.stderr and "{" not in r.stdout

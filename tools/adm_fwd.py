@@ -1,19 +1,32 @@
 #!/usr/bin/env python
-"""ADM fp16-torso forwards at B=4 for rocprofv3."""
+"""ADM fp16-torso forwards at B=4 for rocprofv3.
+
+Set-up (weight packing = ATen fill / copy / cast kernels) and two warm-up forwards run FIRST; then one launch of the
+marker kernel (`ddnm_finalize_psnr_f32`, never part of a forward) tells tools/prof_summary.py / tools/pmc_summary.py
+where the profiled forwards begin, so the tracked summaries hold the forward's own launches only (16 % of
+the r02 "forward" summary was load_state_dict traffic)."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ddnm_amd import ops  # noqa: E402
 from ddnm_amd.guided_diffusion.unet import create_model  # noqa: E402
 
+B = int(os.environ.get("ADM_B", "4"))
 m = create_model(image_size=256, num_channels=256, num_res_blocks=2, attention_resolutions="32,16,8", num_head_channels=64,
                  learn_sigma=True, use_scale_shift_norm=True, resblock_updown=True)
 m.load_state_dict(m.random_state_dict(1))
 m.convert_to_fp16()
-x = torch.randn(4, 3, 256, 256, device="cuda")
-t = torch.full((4,), 500.0, device="cuda")
+x = torch.randn(B, 3, 256, 256, device="cuda")
+t = torch.full((B,), 500.0, device="cuda")
+for _ in range(2):
+    m(x, t)
+torch.cuda.synchronize()
+a = torch.rand(1, 3, 8, 8, device="cuda")
+ops.finalize_psnr(a, a.clone())            # marker: everything after this launch is "the forwards"
+torch.cuda.synchronize()
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     m(x, t)
 torch.cuda.synchronize()

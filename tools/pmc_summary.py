@@ -12,12 +12,18 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNEL = os.environ.get("PMC_KERNEL", "conv3x3_halo_f32_kernel<2, 2, 2, 2>")
+KERNEL_RE = os.environ.get("PMC_KERNEL_RE")          # regular expression over kernel names (several template variants)
+MARKER = os.environ.get("PMC_AFTER_MARKER")          # only dispatches after the last launch of this kernel
 PASSES = os.environ.get("PMC_PASSES", "2 forwards at B=8 per PMC pass")
 
 
 def pivot(path):
     df = pd.read_csv(path)
-    df = df[df.Kernel_Name.str.contains(KERNEL, regex=False)]
+    if MARKER:
+        hit = df[df.Kernel_Name.str.contains(MARKER, regex=False)]
+        if len(hit):
+            df = df[df.Dispatch_Id > hit.Dispatch_Id.max()]
+    df = df[df.Kernel_Name.str.contains(KERNEL_RE, regex=True) if KERNEL_RE else df.Kernel_Name.str.contains(KERNEL, regex=False)]
     return df.pivot_table(index=["Dispatch_Id", "Grid_Size"], columns="Counter_Name", values="Counter_Value",
                           aggfunc="sum").reset_index()
 
@@ -27,11 +33,18 @@ def rocprof_avg_us(db, kernel):
     event-based figure must agree with)."""
     if not db or not os.path.exists(db):
         return None
+    import re
     cur = sqlite3.connect(db).cursor()
-    for name, avg in cur.execute("select name, average from top_kernels"):
-        if kernel in name:
-            return float(avg)          # top_kernels durations are in us (tools/prof_summary.py)
-    return None
+    t0 = 0
+    if MARKER:
+        row = cur.execute("select max(end) from kernels where name like ?", (f"%{MARKER}%",)).fetchone()
+        t0 = row[0] if row and row[0] else 0
+    tot, n = 0.0, 0
+    for name, dur in cur.execute("select name, duration from kernels where start > ?", (t0,)):
+        if (re.search(KERNEL_RE, name) if KERNEL_RE else kernel in name):
+            tot += dur
+            n += 1
+    return tot / n / 1e3 if n else None        # kernels.duration is in ns
 
 
 def main(root, out_json, out_md, stats_db=None):
@@ -47,7 +60,7 @@ def main(root, out_json, out_md, stats_db=None):
     write_b = w.WRITE_SIZE * 1024.0
     from ddnm_amd import build
     res = {
-        "kernel": KERNEL, "launches_in_pass": n, "passes": PASSES,
+        "kernel": KERNEL_RE or KERNEL, "launches_in_pass": n, "passes": PASSES,
         # digest of the sources the profiled binary was built from: bench.py reports these figures only for a loaded
         # library with the same digest (the r01 file went stale the moment a kernel changed)
         "source_digest": build._digest(),
