@@ -47,18 +47,20 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
     constexpr int MAXH = BM == 128 ? 204 : 136;          // (TH+2)*(TW+2) for TW in {8,16,32}
     constexpr int HR = (MAXH + 31) / 32;                 // halo rows staged per thread
     constexpr int BR = BN / 32;
-#ifndef DDNM_HALO_SINGLE_BUFFER
     constexpr int NBUF = 2;        // weight tile double-buffered: one barrier per tap
-#else
-    constexpr int NBUF = 1;
-#endif
-    __shared__ __attribute__((aligned(16))) float Hs[MAXH * LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[NBUF * BN * LDT];
+    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read).
+    // Weight tiles first: [NBUF][BN rows][32 floats = 128 B], UNPADDED -- they arrive by LDS-DMA (lane-linear
+    // destination), so the bank-conflict fix is an XOR swizzle of the 16-byte piece index with (row >> 1) & 7, applied
+    // to the per-lane SOURCE address and to the fragment read address; the halo keeps its 36-float pitch (it is
+    // written through registers, behind the GroupNorm + swish prologue).
+    constexpr int BSF = BN * KC;                          // floats per weight buffer
+    __shared__ __attribute__((aligned(1024))) float lds_all[NBUF * BSF + MAXH * LDT
 #ifdef DDNM_PROBE_LDS_PAD
-    __shared__ float lds_pad[DDNM_PROBE_LDS_PAD];
-    if (p.Cin < 0) lds_pad[threadIdx.x] = 0.f;
+                                                            + DDNM_PROBE_LDS_PAD
 #endif
-
+    ];
+    float* const Bs = lds_all;
+    float* const Hs = lds_all + NBUF * BSF;
     const ddnm_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -82,11 +84,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
         hoff[i] = ok ? (img * p.Hs + sy) * p.Ws + sx : -1;
     }
-    const float* wbase = d.weight + (size_t)(n_tile * BN + prow) * 9 * p.Cin + c4 * 4;
 
     // K range of this workgroup (channel chunks)
     const int nchunks = p.Cin / KC;
+#ifdef DDNM_PROBE_DEPHASE             // timing probe (wrong results): a subset of the FIRST round's workgroups skips the
+                                      // first half of K, so that they run half a tile out of phase for the rest of the launch
+    const bool dephase_short = DDNM_PROBE_DEPHASE == 1 ? (blockIdx.x >= 256 && blockIdx.x < 512)
+                                                       : (blockIdx.x < 512 && ((blockIdx.x >> 3) & 1));
+    const int c_begin = dephase_short ? nchunks / 2 : 0, c_end = nchunks;
+#else
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
+#endif
 
     f32x4 h_st[HR], b_st[BR];
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
@@ -109,10 +117,22 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
             gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + c4 * 4);
         }
     };
-    auto prefetch_b = [&](int chunk, int tap) {
-        const float* wp = wbase + (size_t)tap * p.Cin + chunk * KC;
+    // ---- weight tile of (chunk, tap) -> Bs[buf] by LDS-DMA: one instruction moves 8 rows x 128 B; lane ->
+    // (row = 8*g + lane/8, piece lane%8) and the piece it FETCHES is piece ^ swizzle(row), so the linear image holds the
+    // swizzled layout.  Rows of wave w: 8w + lrow + 32 j, so (row >> 1) & 7 = 4 (w & 1) + (lrow >> 1) for every j.
+    const int lrow = lane >> 3, lpiece = lane & 7;
+    const int wswz = (((wave & 1) << 2) | (lrow >> 1));
+    const unsigned w_rowlen = 9u * (unsigned)p.Cin;
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.weight), 0, (unsigned)p.n_tiles * BN * w_rowlen * 4u, 0x00020000);
+    const unsigned w_voff = (((unsigned)(n_tile * BN + wave * 8 + lrow)) * w_rowlen + (unsigned)((lpiece ^ wswz) * 4)) * 4u;
+    auto issue_w = [&](int chunk, int tap, int buf) {
+        char* dst = reinterpret_cast<char*>(Bs + buf * BSF) + wave * 1024;
+        const unsigned so = ((unsigned)tap * p.Cin + (unsigned)chunk * KC) * 4u;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) b_st[i] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * i) * 9 * p.Cin);
+        for (int j = 0; j < BR; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16,
+                                                     w_voff, so + (unsigned)j * 32u * w_rowlen * 4u, 0, 0);
     };
     auto stage_halo = [&](bool apply_gn = true) {
 #pragma unroll
@@ -127,10 +147,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
             }
         }
     };
-    auto stage_b = [&](int buf) {
+    auto stage_b = [&](int buf) {          // register-staged weights (fused shortcut): the same swizzled image
 #pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[buf * BN * LDT + (prow + 32 * i) * LDT + c4 * 4]) = b_st[i];
+        for (int i = 0; i < BR; ++i) {
+            const int row = prow + 32 * i;
+            *reinterpret_cast<f32x4*>(&Bs[buf * BSF + row * KC + ((c4 ^ ((row >> 1) & 7)) << 2)]) = b_st[i];
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -149,50 +171,81 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
         a_off[i] = (ty * HWd + tx) * LDT + (lane >> 5) * 4;
     }
-    const float* b_frag = Bs + (wn * NT * 32) * LDT + (lane & 31) * LDT + (lane >> 5) * 4;
+    // B fragment of k-step kk: row n = wn*NT*32 + j*32 + (lane & 31), piece (lane >> 5) + 2 kk, swizzled with
+    // (n >> 1) & 7 = ((lane & 31) >> 1) & 7; the k-step enters as an XOR of bits 5-6 of the byte address
+    const int b_frag = ((wn * NT * 32 + (lane & 31)) * KC * 4) + ((((lane >> 5) ^ (((lane & 31) >> 1) & 7))) << 4);
 
     auto mfma_tap = [&](int tap, int buf) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int tap_off = (ky * HWd + kx) * LDT;
-        const float* bf = b_frag + buf * BN * LDT;
+        const char* bbase = reinterpret_cast<const char*>(Bs + buf * BSF);
+#ifdef DDNM_PROBE_NO_FRAG          // timing probe (wrong results): one set of fragment reads per tap instead of four
+        f32x4 a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(bbase + b_frag + j * 32 * KC * 4);
 #pragma unroll
         for (int kk = 0; kk < KC / 8; ++kk) {
-            f32x4 a[MT], b[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off + kk * 8);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(bf + j * 32 * LDT + kk * 8);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
         }
+#else
+        // explicit two-deep fragment pipeline: the reads of k-step kk+1 are in flight under the 16 MFMAs of kk
+        f32x4 a[2][MT], b[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(bbase + b_frag + j * 32 * KC * 4);
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < KC / 8) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a[nxt][i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off + (kk + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    b[nxt][j] = *reinterpret_cast<const f32x4*>(bbase + ((b_frag ^ ((kk + 1) << 5)) + j * 32 * KC * 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[cur][i], b[cur][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
     };
 
-#ifndef DDNM_HALO_SINGLE_BUFFER
-    // ---- weight tile double-buffered: per tap  [write B(s+1) -> other buffer | issue loads B(s+2) |
-    //      MFMA(s) | barrier];  the halo is re-staged between two barriers at every chunk boundary.
+    // ---- weight tile double-buffered, by LDS-DMA: per tap  [barrier: B(s) landed, buffer of B(s-1) free |
+    //      request B(s+1) into it | MFMA(s)];  the halo is re-staged between two barriers at every chunk boundary.
+    // The request flies under the 64 MFMAs per wave of a tap and is drained by the `vmcnt(0)` of the next tap's
+    // barrier; no staging registers, no ds_write pass, no wait on a register destination inside the loop.
 #ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
     if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
 #endif
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
-        prefetch_b(c_begin, 0);
+        issue_w(c_begin, 0, 0);
         stage_halo();
-        stage_b(0);
-        prefetch_b(c_begin, 1);
-        __syncthreads();
         int cur = 0;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
+#pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const bool last_tap = tap == 8, more = chunk + 1 < c_end;
-                if (!last_tap || more) {
-                    stage_b(cur ^ 1);                       // B(s+1) (its loads flew during the previous MFMAs)
-                    // loads for B(s+2)
-                    if (tap < 7) prefetch_b(chunk, tap + 2);
-                    else if (tap == 7) { if (more) { prefetch_b(chunk + 1, 0); prefetch_halo(chunk + 1); } }
-                    else if (more) prefetch_b(chunk + 1, 1);
-                }
+#ifndef DDNM_PROBE_NO_SYNC           // timing probe (wrong results): no barrier per tap
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of B(s) (and of the halo prefetch)
+                __syncthreads();                                        // everybody's; B(s-1) and (tap 0) the halo are free
+#endif
+#ifndef DDNM_PROBE_NO_WL             // timing probe (wrong results): no weight requests inside the tap loop
+                if (!last_tap) issue_w(chunk, tap + 1, cur ^ 1);
+                else if (more) issue_w(chunk + 1, 0, cur ^ 1);
+#endif
+                if (tap == 7 && more) prefetch_halo(chunk + 1);         // registers; staged after tap 8
+#ifndef DDNM_PROBE_NO_PIN
+                __builtin_amdgcn_sched_barrier(0);      // requests in FRONT of the MFMAs (the scheduler sinks them otherwise)
+#endif
 #ifdef DDNM_PROBE_SETPRIO_MFMA      // probe: the MFMA burst of a tap at raised wave priority
                 __builtin_amdgcn_s_setprio(1);
 #endif
@@ -200,37 +253,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 #ifdef DDNM_PROBE_SETPRIO_MFMA
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                __syncthreads();
-                if (last_tap && more) {                     // chunk boundary: every wave is done with Hs
-                    stage_halo();
+                if (last_tap && more) {                     // chunk boundary: every wave must be done with Hs
                     __syncthreads();
+                    stage_halo();
                 }
                 cur ^= 1;
             }
         }
     }
-#else
-    if (c_begin < c_end) {
-        prefetch_halo(c_begin);
-        prefetch_b(c_begin, 0);
-    }
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        for (int tap = 0; tap < 9; ++tap) {
-            __syncthreads();                 // previous MFMAs finished reading Bs (and Hs when tap == 0)
-            if (tap == 0) stage_halo();
-            stage_b(0);
-            __syncthreads();
-            // loads for the next step fly while this step's MFMAs run
-            if (tap < 8) {
-                prefetch_b(chunk, tap + 1);
-            } else if (chunk + 1 < c_end) {
-                prefetch_b(chunk + 1, 0);
-                prefetch_halo(chunk + 1);
-            }
-            mfma_tap(tap, 0);
-        }
-    }
-#endif
     // ---- fused 1x1 shortcut (nin_shortcut / skip_connection of a residual block): extra K chunks that read
     // the block's RAW input (no GroupNorm) at the centre tap and accumulate into the same tile, so the
     // shortcut needs neither its own launch nor an HBM round trip of its output.

@@ -151,12 +151,22 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
                                                                 float* __restrict__ shift,
                                                                 const float* __restrict__ film, int film_stride,
                                                                 float* __restrict__ mean_rstd) {
-    __shared__ double red[256][2];
+    __shared__ double red[4][2];
     __shared__ float mean_s, rstd_s;
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int C = C0 + C1, cpg = C / groups;
     const int c_lo = g * cpg;
     double a = 0.0, q = 0.0;
+    // the affine's own operands do not depend on the statistics: request them first (cpg <= 256 channels per group)
+    float gam = 0.f, bet = 0.f, f_s = 0.f, f_t = 0.f;
+    if (tid < cpg) {
+        gam = gamma[c_lo + tid];
+        bet = beta[c_lo + tid];
+        if (film) {
+            f_s = film[(size_t)b * film_stride + c_lo + tid];
+            f_t = film[(size_t)b * film_stride + C + c_lo + tid];
+        }
+    }
     // channels of the group below C0 come from part0, the rest from part1
     const int n0 = max(0, min(C0, c_lo + cpg) - c_lo);
     const int n1 = cpg - n0;
@@ -174,12 +184,18 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         a += (double)v.x;
         q += (double)v.y;
     }
-    red[tid][0] = a;
-    red[tid][1] = q;
+    // fixed-shape reduction (deterministic): xor-butterfly inside each wave, then the four wave sums in order --
+    // one barrier instead of the eight of an LDS tree (this kernel is pure latency: 101 launches per ADM forward)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        q += __shfl_xor(q, o);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = a; red[tid >> 6][1] = q; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {       // fixed-shape tree: deterministic
-        if (tid < s) { red[tid][0] += red[tid + s][0]; red[tid][1] += red[tid + s][1]; }
-        __syncthreads();
+    if (tid == 0) {
+        red[0][0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        red[0][1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
     if (tid == 0) {
         const double cnt = (double)HW * (double)cpg;
@@ -194,13 +210,14 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         }
     }
     __syncthreads();
-    for (int c = c_lo + tid; c < c_lo + cpg; c += 256) {
-        float sc = rstd_s * gamma[c];
-        float sh = beta[c] - mean_s * sc;
+    if (tid < cpg) {
+        const int c = c_lo + tid;
+        float sc = rstd_s * gam;
+        float sh = bet - mean_s * sc;
         if (film) {
-            const float s1 = 1.0f + film[(size_t)b * film_stride + c];
+            const float s1 = 1.0f + f_s;
             sc = sc * s1;
-            sh = sh * s1 + film[(size_t)b * film_stride + C + c];
+            sh = sh * s1 + f_t;
         }
         scale[(size_t)b * C + c] = sc;
         shift[(size_t)b * C + c] = sh;
@@ -214,7 +231,7 @@ extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int3
     if (!part0 || !gamma || !beta || !scale || !shift || B <= 0 || tpi0 <= 0 || C0 <= 0) return DDNM_E_BADARG;
     if (C1 > 0 && (!part1 || tpi1 <= 0)) return DDNM_E_BADARG;
     const int C = C0 + C1;
-    if (groups <= 0 || C % groups) return DDNM_E_SHAPE;
+    if (groups <= 0 || C % groups || C / groups > 256) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_tiles_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, part0, tpi0, C0, part1, tpi1,
                 C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride, mean_rstd);
     return 0;

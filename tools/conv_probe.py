@@ -21,9 +21,21 @@ OUT = os.path.join(ROOT, "tools", "_build")      # git-ignored, but travels with
 
 VARIANTS = {
     "base": [],
+    "old": None,                                 # a library built beforehand from another source (tools/_build/libprobe_old.so)
     "prio_mfma": ["-DDDNM_PROBE_SETPRIO_MFMA"],
     "prio_half": ["-DDDNM_PROBE_SETPRIO_HALF"],
+    "nostore": ["-DDDNM_PROBE_NO_STORE"],
+    "dephase1": ["-DDDNM_PROBE_DEPHASE=1"],      # blocks 256..511 skip half of their first tile's K (3.1 % less work at 4096 tiles)
+    "dephase2": ["-DDDNM_PROBE_DEPHASE=2"],      # every other group of 8 blocks among the first 512
+    "nogn": ["-DDDNM_PROBE_NO_GN"],
+    "nopin": ["-DDDNM_PROBE_NO_PIN"],
+    "nofrag": ["-DDDNM_PROBE_NO_FRAG"], "nosync": ["-DDDNM_PROBE_NO_SYNC"], "nowl": ["-DDDNM_PROBE_NO_WL"],
+    "all3": ["-DDDNM_PROBE_NO_FRAG", "-DDDNM_PROBE_NO_SYNC", "-DDDNM_PROBE_NO_WL"],
+    "all3ns": ["-DDDNM_PROBE_NO_FRAG", "-DDDNM_PROBE_NO_SYNC", "-DDDNM_PROBE_NO_WL", "-DDDNM_PROBE_NO_STORE", "-DDDNM_PROBE_NO_GN"],
+    "occ1": ["-DDDNM_PROBE_LDS_PAD=8192"],            # round-2 schedule: the compiler sinks the weight prefetch to the end of a tap
 }
+if os.environ.get("ONLY"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 
 # (name, B, C0, C1, Cout, H (input, pre-upsample), k, stride, ups, gn, res, tile)
 SHAPES = [
@@ -51,9 +63,11 @@ SHAPES = [
 
 def build(name, flags):
     so = os.path.join(OUT, f"libprobe_{name}.so")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + flags + \
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + (flags or []) + \
           [os.path.join(CSRC, "conv_igemm_f32.hip"), "-o", so]
-    if not os.path.exists(so) or "--rebuild" in sys.argv:
+    if flags is None:
+        assert os.path.exists(so), so
+    elif not os.path.exists(so) or "--rebuild" in sys.argv:
         subprocess.run(cmd, check=True)
     if "--build-only" in sys.argv:
         return None
@@ -66,6 +80,11 @@ def build(name, flags):
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = [a for a in sys.argv[1:] if not a.startswith("--")] or list(VARIANTS)
+    global SHAPES
+    if os.environ.get("SHAPES") == "big":
+        SHAPES = [s for s in SHAPES if s[0] in ("warmup", "c128_128_256_gn_res", "c128_128_256_plain", "c128_128_256_gn_only",
+                                               "c128_128_256_res_only", "c256cat_128_256_gn", "c128_128_128_gn_res",
+                                               "c256_256_64_gn_res")]
     libs = {n: build(n, VARIANTS[n]) for n in only}
     if "--build-only" in sys.argv:
         return
@@ -76,6 +95,7 @@ def main():
     for (name, B, C0, C1, Cout, H, k, stride, ups, gn, res, tile) in SHAPES:
         Hin = 2 * H if ups else H
         Ho = Hin // stride
+        zero = os.environ.get("ZERO") == "1"         # zero-filled operands: DVFS / power check (MI355X_MICROARCH.md)
         a = torch.randn(B, H, H, C0, device=dev)
         b = torch.randn(B, H, H, C1, device=dev) if C1 else None
         cpad = (Cout + 127) // 128 * 128
@@ -83,6 +103,12 @@ def main():
         # COLD=1: rotate through > 512 MB of weight copies so that no launch finds its weights in L2 / MALL (as inside a forward)
         ncopy = min(64, int(512e6 // (w.numel() * 4)) + 1) if os.environ.get("COLD") == "1" else 1
         wcopies = [w] + [w.clone() for _ in range(ncopy - 1)]
+        if zero:
+            a.zero_()
+            for wc in wcopies:
+                wc.zero_()
+            if b is not None:
+                b.zero_()
         bias = torch.randn(Cout, device=dev)
         sc = torch.randn(B, C0 + C1, device=dev)
         sh = torch.randn(B, C0 + C1, device=dev)
@@ -114,7 +140,8 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
             row.append(flops / (ms * 1e-3) / 1e12)
-        print(f"{name:26s} " + " ".join(f"{v:10.1f}" for v in row), flush=True)
+        print(f"{name:26s} " + " ".join(f"{v:10.1f}" for v in row) + "   us: " +
+              " ".join(f"{flops / (v * 1e12) * 1e6:8.1f}" for v in row), flush=True)
 
 
 if __name__ == "__main__":
