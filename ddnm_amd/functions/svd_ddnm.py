@@ -88,6 +88,60 @@ def _guided_eps(et, grad, coef):
     return out
 
 
+class _GuidanceAhead:
+    """Classifier guidance on its own HIP stream, one reverse step ahead of the UNet.
+
+    The reference evaluates `cls_fn(x, t, classes)` on the INITIAL noise `x` (svd_ddnm.py:49-52; quirk kept), so the
+    guidance term of a step depends only on (x, t, class) -- not on x_t, i.e. not on the UNet chain.  Its ~700 launches
+    (classifier forward + explicit input-gradient backward, many of them latency-bound with a handful of workgroups)
+    therefore run on a second stream while the first stream runs the UNet forward of the same step; the main stream
+    waits on an event right before it combines the two.  Same kernels, same inputs, same results; only the order in
+    which two independent launch sequences reach the GPU changes.  DDNM_CLS_OVERLAP=0 restores the serial order."""
+
+    def __init__(self, cls_fn, x, n, t_values):
+        import collections
+        import os
+        self.cls_fn, self.x, self.n = cls_fn, x, n
+        self.t_values, self.pos = t_values, 0
+        self.serial = os.environ.get("DDNM_CLS_OVERLAP") == "0"
+        self.queue = collections.deque()
+        if not self.serial:
+            self.main = torch.cuda.current_stream()
+            # high priority: the guidance pass is a long chain of small dependent launches (latency-bound), the UNet a
+            # sequence of chip-filling ones -- the chain must not queue behind them, the big kernels soak up the rest
+            self.side = torch.cuda.Stream(device=x.device, priority=int(os.environ.get("DDNM_CLS_PRIO", "-1")))
+            self.side.wait_stream(self.main)             # x (and the operator's set-up) are complete
+            self._launch()
+
+    def _launch(self):
+        if self.pos >= len(self.t_values):
+            return
+        tv = self.t_values[self.pos]
+        self.pos += 1
+        with torch.cuda.stream(self.side):
+            t = torch.full((self.n,), float(tv), device=self.x.device, dtype=torch.float32)
+            cls = torch.full((self.n,), class_num, dtype=torch.long, device=self.x.device)
+            g = self.cls_fn(self.x, t, cls)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.queue.append((tv, g, ev))
+
+    def grad(self, tv, t, cls):
+        """Gradient of the reverse step at timestep `tv` (called AFTER the UNet forward of that step was enqueued)."""
+        if self.serial:
+            return self.cls_fn(self.x, t, cls)
+        tq, g, ev = self.queue.popleft()
+        assert tq == tv, (tq, tv)
+        self.main.wait_event(ev)
+        g.record_stream(self.main)                        # allocated on the side stream, consumed on the main one
+        self._launch()                                    # the next step's guidance starts under this step's tail
+        return g
+
+    def close(self):
+        if not self.serial:
+            self.main.wait_stream(self.side)
+
+
 def _noise_source(noise, like):
     if noise is None:
         def draw(k):
@@ -128,7 +182,10 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
     x0_t = torch.empty_like(x)
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     have_x0 = False
+    guide = None
     with torch.no_grad():
+        if cls_fn is not None:
+            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
             if j < 0:
@@ -142,7 +199,8 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                     et = model(xt, t)
                 else:
                     cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
-                    et = _guided_eps(model(xt, t, cls), cls_fn(x, t, cls), float((1 - at).sqrt()))
+                    eps = model(xt, t, cls)
+                    et = _guided_eps(eps, guide.grad(i, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:
                     et = et[:, :3]
                 s = ops.step_scalars(at, at_next, eta)
@@ -160,6 +218,8 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
             if record is not None:
                 record(k, "x0_t", x0_t)
                 record(k, "xt_next", xt)
+        if guide is not None:
+            guide.close()
     return _finish(xt, x0_t, return_cpu)
 
 
@@ -188,7 +248,10 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
     x0_t = torch.empty_like(x)
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     have_x0 = False
+    guide = None
     with torch.no_grad():
+        if cls_fn is not None:
+            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
             if j < 0:
@@ -202,7 +265,8 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                     et = model(xt, t)
                 else:
                     cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
-                    et = _guided_eps(model(xt, t, cls), cls_fn(x, t, cls), float((1 - at).sqrt()))
+                    eps = model(xt, t, cls)
+                    et = _guided_eps(eps, guide.grad(i, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:
                     et = et[:, :3].contiguous()
                 a, sigma_t = at_next.sqrt(), (1 - at_next).sqrt()
@@ -218,4 +282,6 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                 assert have_x0
                 ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
+        if guide is not None:
+            guide.close()
     return _finish(xt, x0_t, return_cpu)
