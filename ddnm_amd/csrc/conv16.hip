@@ -64,10 +64,13 @@ struct C16Geom {
     // (low resolutions: every weight byte is used by a handful of pixel tiles and a step's MFMAs are shorter than an L2
     // round trip), so they keep TWO weight tiles ahead of the one being multiplied; the 1-tap GEMM form needs a new
     // pixel tile per step as well
-    static constexpr int NWB = (MT == 2 && WNW == 4) ? 3 : 2;
-    static constexpr int NHB = (TAPS == 1 && MT == 2) ? 3 : 2;
+    // ... and the 64-pixel GEMM tile (1x1 convolutions of the 8^2 .. 32^2 attention blocks, the im2col'ed 8^2 level:
+    // <= 16 steps per workgroup, every one a cold weight tile) keeps THREE tiles ahead: those launches are chains of
+    // HBM round trips, and their rate is (tiles in flight) / latency
+    static constexpr int NWB = (TAPS == 1 && MT == 1 && WNW == 4) ? 4 : ((MT == 2 && WNW == 4) ? 3 : 2);
+    static constexpr int NHB = TAPS == 1 ? (MT == 1 ? 4 : (MT == 2 ? 3 : 2)) : 2;
     static constexpr int LDS_TILES = NHB * HBYTES + NWB * WBYTES;
-    static constexpr int LDS_MAIN = LDS_TILES + 512;                    // + GroupNorm scale | shift of one 64-channel chunk
+    static constexpr int LDS_MAIN = LDS_TILES + (TAPS == 9 ? 512 : 0);  // + GroupNorm scale | shift of one 64-channel chunk
     static constexpr int LDS_EPI = WNW == 4 ? 8 * (MT * 32) * C16_EPITCH + 2 * C16_BN * 2 * 4 : 0;
     static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
@@ -310,8 +313,13 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     const unsigned wrow = (unsigned)(TAPS * Cin);
     int hb = 0, wb = 0;
     bool pend = false;                 // the previous step requested a group that may still be in flight
+    int ahead = 0;                     // 1-tap form: request groups younger than the one the next step multiplies
     auto wait_tiles = [&]() {
-        if (LA == 2 && pend) {
+        if (TAPS == 1 && LA > 1) {
+            if (ahead >= 2 && LA >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GRP) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (LA == 2 && pend) {
             if constexpr (GRP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GRP) : "memory");
         } else {
@@ -326,9 +334,17 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         issue_main_halo(c_begin, 0);
         if (fuse_gn) issue_gn(c_begin);
         issue_w(r_w, wrow, (unsigned)(c_begin * C16_KC), 0);
-        if (LA == 2 && (TAPS == 9 || c_begin + 1 < c_end)) {
-            if (TAPS == 1) issue_main_halo(c_begin + 1, 1);
-            issue_w(r_w, wrow, (unsigned)(TAPS == 9 ? Cin + c_begin * C16_KC : (c_begin + 1) * C16_KC), 1);
+        if (TAPS == 1) {
+            // tiles of the steps c_begin + 1 .. c_begin + LA - 1 (the first one was requested above)
+#pragma unroll
+            for (int a = 1; a < LA; ++a)
+                if (c_begin + a < c_end) {
+                    issue_main_halo(c_begin + a, a);
+                    issue_w(r_w, wrow, (unsigned)((c_begin + a) * C16_KC), a);
+                    ahead = a;
+                }
+        } else if (LA == 2) {
+            issue_w(r_w, wrow, (unsigned)(Cin + c_begin * C16_KC), 1);
             pend = true;
         }
         if (fuse_gn) {
@@ -371,6 +387,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
                     issue_w(r_w, wrow, (unsigned)(t2 * Cin + c2 * C16_KC), wb + LA >= G::NWB ? wb + LA - G::NWB : wb + LA);
                     pend = true;
                 }
+                // 1-tap form: the step after this one finds min(LA - 1, steps left after it) younger groups in flight
+                if (TAPS == 1) { const int left = c_end - 2 - c; ahead = left < LA - 1 ? (left < 0 ? 0 : left) : LA - 1; }
             };
 #if DDNM_P16_LATE_DMA
             // the next tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
@@ -687,7 +705,8 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     pl->taps = d->ksize == 3 ? 9 : 1;
     pl->n_tiles = (d->Cout + C16_BN - 1) / C16_BN;
     long tiles_of[5] = {0, 0, 0, 0, 0};
-    for (int mt = 2; mt <= 4; mt += 2) {
+    for (int mt = 1; mt <= 4; mt += (mt == 1 ? 1 : 2)) {
+        if (mt == 1 && pl->taps != 1) continue;          // 64-pixel tiles: flat GEMM form only
         const int bm = 64 * mt;
         if (pl->taps == 9) {
             int tw = 32;
@@ -702,6 +721,13 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     // the 256-pixel tile unless it cannot give most of the 256 CUs a workgroup and the 128-pixel tile can
     int best_mt = tiles_of[4] > 0 ? 4 : (tiles_of[2] > 0 ? 2 : 0);
     if (tiles_of[4] < 200 && tiles_of[2] > tiles_of[4]) best_mt = 2;
+#ifndef DDNM_P16_MT1
+#define DDNM_P16_MT1 1              // build-time probe switch: 0 = no 64-pixel tiles
+#endif
+    // 1x1 convolutions / im2col'ed GEMMs whose 128-pixel tiling leaves half of the CUs without a workgroup (qkv and
+    // proj_out of the 8^2 .. 32^2 attention blocks: 8 .. 96 tiles, each a chain of <= 16 steps): 64-pixel tiles double the
+    // workgroups of the one round and halve its length; split-K launches get half as many fp32 slabs
+    if (DDNM_P16_MT1 && pl->taps == 1 && best_mt == 2 && tiles_of[2] <= 128 && tiles_of[1] > tiles_of[2]) best_mt = 1;
     if (best_mt == 0) return false;
     pl->MT = best_mt;
     const int bm = 64 * best_mt;
@@ -813,7 +839,8 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
         else { DDNM_LAUNCH((conv16_kernel<9, 2, 4>), grid, dim3(512), 0, s, p); }
     } else {
         if (pl.MT == 4) { DDNM_LAUNCH((conv16_kernel<1, 4, 4>), grid, dim3(512), 0, s, p); }
-        else { DDNM_LAUNCH((conv16_kernel<1, 2, 4>), grid, dim3(512), 0, s, p); }
+        else if (pl.MT == 2) { DDNM_LAUNCH((conv16_kernel<1, 2, 4>), grid, dim3(512), 0, s, p); }
+        else { DDNM_LAUNCH((conv16_kernel<1, 1, 4>), grid, dim3(512), 0, s, p); }
     }
     if (pl.ksplit > 1) {
         const int tpi = pl.stats_tiles;

@@ -24,7 +24,7 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
             "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None, "maxm0": ["-DDDNM_P16_WMAJOR_MAXM=0"], "maxm16": ["-DDDNM_P16_WMAJOR_MAXM=16"],
             "maxm64": ["-DDDNM_P16_WMAJOR_MAXM=64"],
-            "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
+            "mt1off": ["-DDDNM_P16_MT1=0"], "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
 if os.environ.get("ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
@@ -62,7 +62,8 @@ ONE = [("warm", 256, 256, 256, 3, 1),
        ("9216->1024@8 1x1", 9216, 1024, 8, 1, 0), ("1024->3072@32 1x1", 1024, 3072, 32, 1, 0),
        ("1024->1024@16 1x1", 1024, 1024, 16, 1, 0), ("1024->3072@16 1x1", 1024, 3072, 16, 1, 0),
        ("1024->1024@8 1x1", 1024, 1024, 8, 1, 0), ("1024->3072@8 1x1", 1024, 3072, 8, 1, 0),
-       ("512->1536@32 1x1", 512, 1536, 32, 1, 0), ("512->512@32 1x1", 512, 512, 32, 1, 0)]
+       ("512->1536@32 1x1", 512, 1536, 32, 1, 0), ("512->512@32 1x1", 512, 512, 32, 1, 0),
+       ("18432->1024@8 1x1", 18432, 1024, 8, 1, 0), ("4608->512@8 1x1", 4608, 512, 8, 1, 0)]
 for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE, "mid": MID}.get(os.environ.get("SHAPES"), None) or [("warm", 256, 256, 256, 3, 1), ("64->256@256 res", 64, 256, 256, 3, 1), ("128->256@256 res", 128, 256, 256, 3, 1),
                                    ("256->256@256 res", 256, 256, 256, 3, 1), ("256->256@256", 256, 256, 256, 3, 0),
                                    ("512->256@256", 512, 256, 256, 3, 0), ("1024->256@256", 1024, 256, 256, 3, 0),
