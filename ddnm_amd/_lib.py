@@ -58,6 +58,9 @@ class Conv16Desc(Structure):
         ("src1", c_void_p), ("gn_scale", c_void_p), ("gn_shift", c_void_p),
         ("C0", c_int32), ("gn_silu", c_int32),
         ("out_nchw_f32", c_int32), ("reserved", c_int32),
+        ("fin_gamma", c_void_p), ("fin_beta", c_void_p), ("fin_film", c_void_p),
+        ("fin_scale", c_void_p), ("fin_shift", c_void_p),
+        ("fin_eps", c_float), ("fin_film_stride", c_int32), ("fin_groups", c_int32), ("reserved2", c_int32),
     ]
 
 
@@ -102,6 +105,7 @@ PROTOTYPES = {
     "ddnm_conv3x3_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv16": (c_int32, [POINTER(Conv16Desc), c_void_p]),
     "ddnm_conv16_supported": (c_int32, [POINTER(Conv16Desc)]),
+    "ddnm_conv16_fuses_fin": (c_int32, [POINTER(Conv16Desc)]),
     "ddnm_conv16_workspace_floats": (c_int64, [POINTER(Conv16Desc)]),
     "ddnm_conv16_stats_tiles": (c_int32, [POINTER(Conv16Desc)]),
     "ddnm_gn_apply_h16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
@@ -188,7 +192,7 @@ class DDNMHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def lib():

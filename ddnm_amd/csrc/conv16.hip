@@ -666,10 +666,121 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const 
     }
 }
 
+// =====================================================================================
+// split-K reduction that also FINALIZES the consumer's GroupNorm (ddnm_conv16_desc::fin_*): one workgroup per
+// (image, slab of CS channels = whole groups) walks ALL pixels of the image, so it holds the complete per-channel
+// sums of the rounded output and can turn them into the affine the next convolution applies -- no
+// gn_finalize_tiles launch between a split-K convolution and its consumer (low-resolution levels: <= 1024 pixels).
+// Thread = one float4 channel column x one pixel row of 256 / (CS/4); fp32 partials per thread, fp64 combination in a
+// fixed order (no atomics: repeated launches are bit-identical).
+// =====================================================================================
+static __global__ __launch_bounds__(256) void conv16_splitk_reduce_fin_kernel(const Conv16Args p, int CS) {
+    __shared__ f32x4 red[2][256];
+    __shared__ double chan[2][64];
+    __shared__ float mr[2][16];
+    const ddnm_conv16_desc& d = p.d;
+    const int b = blockIdx.x, cb = blockIdx.y * CS;
+    const int c4n = CS >> 2, rows = 256 / c4n;
+    const int hw = d.H * d.W;
+    const size_t slab = (size_t)p.M * d.Cout;
+    const int tid = threadIdx.x;
+    const int c4 = tid % c4n, prow = tid / c4n, n = cb + c4 * 4;
+    const _Float16* res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* out = reinterpret_cast<_Float16*>(d.out);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    f32x4 add = {0.f, 0.f, 0.f, 0.f};
+    if (d.bias) add = *reinterpret_cast<const f32x4*>(d.bias + n);
+    // the affine's own operands do not depend on the sums: request them first (threads 0 .. CS-1, one channel each)
+    float gam = 0.f, bet = 0.f, f_s = 0.f, f_t = 0.f;
+    if (tid < CS) {
+        gam = d.fin_gamma[cb + tid];
+        bet = d.fin_beta[cb + tid];
+        if (d.fin_film) {
+            f_s = d.fin_film[(size_t)b * d.fin_film_stride + cb + tid];
+            f_t = d.fin_film[(size_t)b * d.fin_film_stride + d.Cout + cb + tid];
+        }
+    }
+    for (int pp = prow; pp < hw; pp += rows) {
+        const size_t o = ((size_t)b * hw + pp) * d.Cout + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(d.workspace + o);
+#pragma unroll 4
+        for (int k = 1; k < p.ksplit; ++k) v = v + *reinterpret_cast<const f32x4*>(d.workspace + o + k * slab);
+        v = v + add;
+        if (res) {
+            size_t ro = o;
+            if (d.res_ups) {
+                const int oy = pp / d.W, ox = pp - oy * d.W;
+                ro = (((size_t)b * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1)) * d.Cout + n;
+            }
+            const half4 r4 = *reinterpret_cast<const half4*>(res + ro);
+            v = v + f32x4{(float)r4.x, (float)r4.y, (float)r4.z, (float)r4.w};
+        }
+        const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<half4*>(out + o) = h;
+        const f32x4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+        s += f;
+        ss += f * f;
+    }
+    red[0][tid] = s;
+    red[1][tid] = ss;
+    __syncthreads();
+    if (tid < CS) {                                  // channel cb + tid: its column's pixel rows, in order
+        const int col = tid >> 2, e = tid & 3;
+        double a = 0.0, q = 0.0;
+        for (int r = 0; r < rows; ++r) {
+            a += (double)red[0][r * c4n + col][e];
+            q += (double)red[1][r * c4n + col][e];
+        }
+        chan[0][tid] = a;
+        chan[1][tid] = q;
+        if (d.stats_out)                             // one tile per image: other consumers (skip concats) finalize from it
+            *reinterpret_cast<float2*>(d.stats_out + ((size_t)b * d.Cout + cb + tid) * 2) = float2{(float)a, (float)q};
+    }
+    __syncthreads();
+    const int cpg = d.Cout / d.fin_groups, ng = CS / cpg;
+    if (tid < ng) {
+        double a = 0.0, q = 0.0;
+        for (int j = 0; j < cpg; ++j) { a += chan[0][tid * cpg + j]; q += chan[1][tid * cpg + j]; }
+        const double cnt = (double)hw * (double)cpg;
+        const double mean = a / cnt;
+        double var = q / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mr[0][tid] = (float)mean;
+        mr[1][tid] = (float)(1.0 / sqrt(var + (double)d.fin_eps));
+    }
+    __syncthreads();
+    if (tid < CS) {
+        const int g = tid / cpg;
+        float sc = mr[1][g] * gam;
+        float sh = bet - mr[0][g] * sc;
+        if (d.fin_film) {                            // FiLM: GN(x)*(1+s)+t  (guided_diffusion/unet.py:248-251)
+            const float s1 = 1.0f + f_s;
+            sc = sc * s1;
+            sh = sh * s1 + f_t;
+        }
+        d.fin_scale[(size_t)b * d.Cout + cb + tid] = sc;
+        d.fin_shift[(size_t)b * d.Cout + cb + tid] = sh;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct Plan16 {
     int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
+    int fin_cs;          // > 0: the split-K reduction finalizes the consumer's GroupNorm, slabs of fin_cs channels
 };
+
+// channel slab of the finalizing reduction (0: this launch cannot / need not finalize): whole groups, 16 .. 64 channels,
+// images of at most 1024 pixels (one workgroup walks all of them)
+static int fin_slab16(const ddnm_conv16_desc* d, int ksplit) {
+    if (ksplit <= 1 || !d->fin_gamma || !d->fin_beta || !d->fin_scale || !d->fin_shift) return 0;
+    if (d->fin_groups <= 0 || d->Cout % d->fin_groups || d->out_nchw_f32) return 0;
+    const int cpg = d->Cout / d->fin_groups;
+    if (cpg % 4 || cpg > 64 || d->H * d->W > 1024) return 0;
+    int cs = cpg;
+    while (cs < 16) cs *= 2;
+    if (d->Cout % cs || cs / cpg > 16) return 0;
+    return cs;
+}
 
 // pixel tiles per image of the split-K reduction: enough (image, tile, 256-channel slab) workgroups to cover the chip
 // twice, at least 4 pixels per tile
@@ -688,6 +799,7 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     if (d->Cin <= 0 || d->Cin % C16_KC || d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return false;
     if (d->ksize != 1 && d->ksize != 3) return false;
     pl->small = 0;
+    pl->fin_cs = 0;
     if (d->out_nchw_f32) {
         // fp32 NCHW output with <= 32 channels: 256-pixel x 32-channel tiles, no residual / shortcut / statistics
         if (d->ksize != 3 || d->Cout > 32 || d->ups || d->res || d->skip0 || d->stats_out) return false;
@@ -760,7 +872,9 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
         if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;
-    if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
+    pl->fin_cs = fin_slab16(d, ks);
+    if (pl->fin_cs > 0) pl->stats_tiles = 1;
+    else if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
     else pl->stats_tiles = (pl->taps == 9 || hw % bm == 0) ? hw / bm : 0;
     return true;
 }
@@ -768,6 +882,11 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
 extern "C" int ddnm_conv16_supported(const ddnm_conv16_desc* d) {
     Plan16 pl;
     return d && plan16(d, &pl) ? 1 : 0;
+}
+
+extern "C" int ddnm_conv16_fuses_fin(const ddnm_conv16_desc* d) {
+    Plan16 pl;
+    return d && plan16(d, &pl) && pl.fin_cs > 0 ? 1 : 0;
 }
 
 extern "C" int64_t ddnm_conv16_workspace_floats(const ddnm_conv16_desc* d) {
@@ -842,7 +961,9 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
         else if (pl.MT == 2) { DDNM_LAUNCH((conv16_kernel<1, 2, 4>), grid, dim3(512), 0, s, p); }
         else { DDNM_LAUNCH((conv16_kernel<1, 1, 4>), grid, dim3(512), 0, s, p); }
     }
-    if (pl.ksplit > 1) {
+    if (pl.fin_cs > 0) {
+        DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel, dim3(d->B, d->Cout / pl.fin_cs), dim3(256), 0, s, p, pl.fin_cs);
+    } else if (pl.ksplit > 1) {
         const int tpi = pl.stats_tiles;
         DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 255) / 256), dim3(256), 0, s, p, tpi);
     }

@@ -246,7 +246,7 @@ extern "C" int ddnm_embedding_add_f32(float* emb, const float* table, const int6
 
 // ABI version: bumped whenever a descriptor struct or a prototype of include/ddnm_hip.h changes
 // (2: ddnm_conv16_desc and the fp16-activation entry points, ddnm_build_digest, ddnm_sizeof).
-extern "C" int ddnm_version(void) { return 2; }
+extern "C" int ddnm_version(void) { return 3; }
 
 // sha256 of the sources + flags this binary was compiled from (ddnm_amd/build.py passes it with -D); the loader
 // (ddnm_amd/_lib.py) compares it with the digest of the sources next to it and refuses a stale binary.

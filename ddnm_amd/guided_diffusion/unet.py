@@ -322,6 +322,12 @@ class UNetModel:
         return self._ws
 
     def _gn(self, x0, x1, name, film=None):
+        if x1 is None and isinstance(x0, ops.Act) and x0.gn is not None and x0.gn[2] == name \
+                and os.environ.get("DDNM_NO_FUSED_FIN") != "1":
+            # already finalized by the launch that produced x0 (its split-K reduction pass): no launch here
+            sc, sh, _ = x0.gn
+            x0.gn = None
+            return sc, sh
         f, fs = (None, 0) if film is None else (film, self.film_total)
         return ops.group_norm_affine(x0, x1, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws,
                                      film=f, film_stride=fs)
@@ -417,36 +423,47 @@ class UNetModel:
         col = ops.im2col16(x0, x1, gn, silu)
         return ops.conv16(col, w16.reshape(w16.shape[0], 1, -1), cout, 1, **kw)
 
-    def _res16(self, n, L, x0, x1, film_all):
+    def _fin(self, name, film=None):
+        """What a producing convolution needs to finalize the GroupNorm `name` over its own output in its split-K
+        reduction pass (ops.conv16 `fin=`; no effect on launches that are not split)."""
+        f, fs = (None, 0) if film is None else (film, self.film_total)
+        return (name, self.w[name + ".weight"], self.w[name + ".bias"], f, fs, GN_EPS, self._ws)
+
+    def _next_fin(self, L, n):
+        """`fin` of the GroupNorm a following layer opens with (single-source consumers only)."""
+        return self._fin(n + (".in_layers.0" if L[0] == "res" else ".norm"))
+
+    def _res16(self, n, L, x0, x1, film_all, next_fin=None):
         w = self.w
         cin, cout, mode = L[1], L[2], L[3]
         film = film_all[:, self._film_off[n]:]
         gn1 = self._gn(x0, x1, n + ".in_layers.0")
         b1, b2 = w[n + ".in_layers.2.bias"], w[n + ".out_layers.3.bias"]
         k1, k2 = n + ".in_layers.2.weight", n + ".out_layers.3.weight"
+        fin2 = self._fin(n + ".out_layers.0", film)
         if mode == "down":          # AvgPool2d on both branches (unet.py:237-242)
             hp = ops.Act(ops.gn_apply16(x0, None, gn1, True, pool=True))
             xs = ops.gn_apply16(x0, None, None, False, pool=True)
-            h = self._conv3x3_16(k1, cout, hp, None, None, bias=b1)
+            h = self._conv3x3_16(k1, cout, hp, None, None, bias=b1, fin=fin2)
             gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
-            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs)
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs, fin=next_fin)
         if mode == "up":            # nearest x2 on both branches: operand through `ups`, residual through `res_ups`
-            h = self._conv3x3_16(k1, cout, x0, None, gn1, bias=b1, ups=True)
+            h = self._conv3x3_16(k1, cout, x0, None, gn1, bias=b1, ups=True, fin=fin2)
             gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
-            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0, res_ups=True)
-        h = self._conv3x3_16(k1, cout, x0, x1, gn1, bias=b1)
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0, res_ups=True, fin=next_fin)
+        h = self._conv3x3_16(k1, cout, x0, x1, gn1, bias=b1, fin=fin2)
         gn2 = self._gn(h, None, n + ".out_layers.0", film=film)
         if cin == cout:
             assert x1 is None
-            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0)
+            return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=x0, fin=next_fin)
         B, H, W, _ = h.t.shape
         if ops.conv16_supported(B, H, W, cout, cout, 3):      # 1x1 shortcut fused as extra K chunks over the raw input
             return self._conv3x3_16(k2, cout, h, None, gn2, bias=w[n + ".out_plus_skip.bias"], skip=(x0, x1),
-                                    skip_weight=w[n + ".skip_connection.weight.h16.flat"])
+                                    skip_weight=w[n + ".skip_connection.weight.h16.flat"], fin=next_fin)
         raw = x0.t if x1 is None else ops.gn_apply16(x0, x1, None, False)      # materialised concat of the raw tensors
         xs = ops.conv16(raw, w[n + ".skip_connection.weight.h16"], cout, 1, bias=w[n + ".skip_connection.bias"],
                         emit_stats=False)
-        return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs)
+        return self._conv3x3_16(k2, cout, h, None, gn2, bias=b2, res=xs, fin=next_fin)
 
     def _attn16(self, n, x):
         w = self.w
@@ -460,11 +477,12 @@ class UNetModel:
         o = ops.attn16(qkv.t, C)
         return ops.conv16(o, w[n + ".proj_out.weight.h16"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
 
-    def _run16(self, prefix, layers, h, skip, film_all):
+    def _run16(self, prefix, layers, h, skip, film_all, next_fin=None):
         for j, L in enumerate(layers):
             n = f"{prefix}.{j}"
             if L[0] == "res":
-                h = self._res16(n, L, h, skip if j == 0 else None, film_all)
+                nf = self._next_fin(layers[j + 1], f"{prefix}.{j + 1}") if j + 1 < len(layers) else next_fin
+                h = self._res16(n, L, h, skip if j == 0 else None, film_all, nf)
             else:
                 h = self._attn16(n, h)
         return h
@@ -475,10 +493,13 @@ class UNetModel:
         h = ops.nchw_to_nhwc16(x.float().contiguous(), CIN_PAD_F16)
         h = ops.conv16(h, w[n0 + ".weight.h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
         hs = [h]
+        nblk = len(self.input_blocks)
         for i, layers in enumerate(self.input_blocks):
             if i == 0:
                 continue
-            h = self._run16(f"input_blocks.{i}", layers, h, None, film_all)
+            # the GroupNorm that opens the NEXT block reads this block's output alone (no concat on the way down)
+            nxt = (self.input_blocks[i + 1], f"input_blocks.{i + 1}.0") if i + 1 < nblk else (self.middle_block, "middle_block.0")
+            h = self._run16(f"input_blocks.{i}", layers, h, None, film_all, self._next_fin(nxt[0][0], nxt[1]))
             hs.append(h)
         h = self._run16("middle_block", self.middle_block, h, None, film_all)
         for i, layers in enumerate(self.output_blocks):

@@ -90,10 +90,13 @@ _NO_FUSED_GN = _os.environ.get("DDNM_NO_FUSED_GN") == "1"      # A/B switch for 
 class Act:
     """An NHWC activation plus, when its producer could emit them, the GroupNorm partials of it
     (per-(M tile, channel) sum / sum of squares written by the convolution epilogue)."""
-    __slots__ = ("t", "stats", "tiles")
+    __slots__ = ("t", "stats", "tiles", "gn")
 
-    def __init__(self, t, stats=None, tiles=0):
+    def __init__(self, t, stats=None, tiles=0, gn=None):
         self.t, self.stats, self.tiles = t, stats, tiles
+        # (scale, shift, name): the affine of the consumer GroupNorm `name`, already finalized by the producing launch
+        # (split-K reduction pass, ddnm_conv16_desc::fin_*); valid until the next finalize reuses the workspace
+        self.gn = gn
 
 
 def conv_fuses_skip(B, H, W, cin, cout):
@@ -317,7 +320,7 @@ def conv16_supported(B, H, W, cin, cout, ksize, ups=False):
 
 
 def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=None, res=None, res_ups=False, ups=False,
-           skip=None, skip_weight=None, emit_stats=True, out=None):
+           skip=None, skip_weight=None, emit_stats=True, out=None, fin=None):
     """fp16 NHWC convolution of the `use_fp16` torso (include/ddnm_hip.h::ddnm_conv16_desc).  The operand is
     concat_c(src, src1) [B,Hs,Ws,Cin] fp16: raw with `gn` = (scale, shift) (3x3 only: GroupNorm affine + swish fused,
     applied in LDS) or already activated.  Returns an `Act` whose tensor is fp16 [B,H,W,cout] and whose GroupNorm
@@ -334,6 +337,16 @@ def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=N
     if out is None:
         out = torch.empty(B, H, W, cout, dtype=torch.float16, device=src.device)
     d.out = _p(_f16c(out, "out"))
+    fused_fin = False
+    if fin is not None and emit_stats:
+        # fin = (name, gamma, beta, film or None, film_stride, eps, workspace): the GroupNorm that will consume `out`
+        name, gamma, beta, film, film_stride, eps, ws = fin
+        d.fin_gamma, d.fin_beta, d.fin_film = _p(gamma), _p(beta), _p(film)
+        d.fin_scale, d.fin_shift = _p(ws.scale), _p(ws.shift)
+        d.fin_eps, d.fin_film_stride, d.fin_groups = eps, film_stride, 32
+        fused_fin = ws.scale.numel() >= B * cout and L.ddnm_conv16_fuses_fin(ctypes.byref(d)) == 1
+        if not fused_fin:
+            d.fin_gamma = None
     stats, tiles = None, 0
     if emit_stats:
         tiles = L.ddnm_conv16_stats_tiles(ctypes.byref(d))
@@ -358,7 +371,7 @@ def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=N
         flops = 2.0 * B * H * W * cout * (ksize * ksize * d.Cin + d.SC0 + d.SC1)
         _timer.records.append((f"conv16<{ksize}x{ksize}>", flops, e0, e1))
         _timer.shapes.append((B, H, W, d.Cin, cout, ksize, 1, int(ups), d.SC0 + d.SC1, False, res is not None))
-    return Act(out, stats, tiles)
+    return Act(out, stats, tiles, gn=(fin[6].scale, fin[6].shift, fin[0]) if fused_fin else None)
 
 
 def conv16_out(src, weight, cout, bias=None, gn=None, gn_silu=True):

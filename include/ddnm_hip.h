@@ -28,7 +28,7 @@ extern "C" {
 #define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
 #define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
 
-int ddnm_version(void);                 /* ABI version, currently 2 (bumped on every struct / prototype change) */
+int ddnm_version(void);                 /* ABI version, currently 3 (bumped on every struct / prototype change) */
 const char* ddnm_build_digest(void);    /* sha256 of the sources + flags this binary was built from (build.py) */
 int ddnm_sizeof(int which);             /* sizeof of 0: ddnm_conv_desc, 1: ddnm_gemm_desc, 2: ddnm_conv16_desc,
                                            3: ddnm_step_scalars as compiled into the binary (-1: unknown index) */
@@ -170,9 +170,24 @@ typedef struct ddnm_conv16_desc {
     int32_t out_nchw_f32;     /* 1: the network's output convolution (unet.py:627-631, `.type(x.dtype)` :664): 3x3,
                                  Cout <= 32 (weight packed to 32 rows or more), fp32 NCHW result, no res / skip / stats */
     int32_t reserved;
+    /* Optional: finalize the CONSUMER's GroupNorm inside the split-K reduction pass.  When ddnm_conv16_fuses_fin(d)
+       == 1 the launch also writes the affine of GroupNorm(fin_groups, Cout, fin_eps)(+ FiLM rows [s | t]) over ITS OWN
+       OUTPUT -- scale / shift [B][Cout], what ddnm_gn_finalize_tiles_f32 would produce from stats_out -- so the
+       convolution that consumes the output needs no finalize launch in between (guided_diffusion/nn.py:17-19,
+       unet.py:196-205,248-251).  stats_out then holds ONE tile per image (ddnm_conv16_stats_tiles(d) == 1). */
+    const float* fin_gamma;   /* [Cout] or NULL (no fused finalize) */
+    const float* fin_beta;    /* [Cout] */
+    const float* fin_film;    /* rows [s(0..Cout) | t(0..Cout)], row b at fin_film + b*fin_film_stride, or NULL */
+    float* fin_scale;         /* [B][Cout] */
+    float* fin_shift;         /* [B][Cout] */
+    float fin_eps;
+    int32_t fin_film_stride;
+    int32_t fin_groups;
+    int32_t reserved2;
 } ddnm_conv16_desc;
 
 int ddnm_conv16(const ddnm_conv16_desc* d, void* stream);
+int ddnm_conv16_fuses_fin(const ddnm_conv16_desc* d);     /* 1: this launch will write fin_scale / fin_shift */
 int ddnm_conv16_supported(const ddnm_conv16_desc* d);
 int64_t ddnm_conv16_workspace_floats(const ddnm_conv16_desc* d);
 int ddnm_conv16_stats_tiles(const ddnm_conv16_desc* d);   /* 0: this launch cannot emit stats_out */

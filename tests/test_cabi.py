@@ -38,7 +38,7 @@ def test_prototypes_match_header():
 
 def test_version_and_error_strings(lib):
     from ddnm_amd import _lib
-    assert lib.ddnm_version() == _lib.ABI_VERSION == 2
+    assert lib.ddnm_version() == _lib.ABI_VERSION == 3
     assert b"shape" in lib.ddnm_error_string(-2)
     assert b"bad argument" in lib.ddnm_error_string(-1)
     assert lib.ddnm_error_string(0) == b"success"
@@ -66,7 +66,7 @@ def test_conv16_struct_layout_matches_header():
     fields = re.findall(r"\b(?:const\s+)?(?:void|float|int32_t|int64_t)\s*\*?\s*([A-Za-z0-9_, \*]+);", body)
     names = [n.strip().lstrip("*") for grp in fields for n in grp.split(",")]
     assert names == [f[0] for f in Conv16Desc._fields_]
-    assert ctypes.sizeof(Conv16Desc) == 10 * 8 + 8 + 10 * 4 + 3 * 8 + 4 * 4
+    assert ctypes.sizeof(Conv16Desc) == 10 * 8 + 8 + 10 * 4 + 3 * 8 + 4 * 4 + 5 * 8 + 4 * 4
 
 
 def test_binary_identifies_itself(lib):
@@ -127,7 +127,7 @@ def test_conv16_plans_without_a_gpu(lib):
     assert plan(4, 64, 512, 512, 3) == (True, 0, 32)                # 256 tiles of 128 pixels
     ok, ws, tiles = plan(4, 16, 1024, 1024, 3)                      # 32 tiles -> 8 slices of fp32 slabs
     assert ok and ws == 8 * 4 * 16 * 16 * 1024 and tiles > 0
-    assert plan(4, 16, 1024, 1024, 1) == (True, 0, 2)               # 1x1 with K <= 1024: never sliced
+    assert plan(4, 16, 1024, 1024, 1) == (True, 0, 4)               # 1x1 with K <= 1024: never sliced; 64-pixel tiles
     ok, ws, _ = plan(4, 8, 9216, 1024, 1)                           # the im2col'ed 8x8 level: K = 9216 is sliced
     assert ok and ws > 0
     assert plan(4, 8, 1024, 1024, 3)[0] is False                    # 8x8 images have no 3x3 pixel tile (im2col route)

@@ -227,3 +227,60 @@ def test_attn16_matches_legacy_qkv_attention(hip, B, T, C):
     torch.cuda.synchronize()
     err = rel(got.float().cpu().reshape(B, T, C).permute(0, 2, 1), ref)
     assert err < 2e-3, err                                  # probabilities rounded to fp16 like the reference
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,film", [(4, 1024, 1024, 16, 3, True), (2, 512, 512, 16, 3, False),
+                                                 (4, 512, 1024, 32, 3, True), (4, 9 * 512, 512, 8, 1, True),
+                                                 (1, 9 * 256, 256, 8, 1, False)])
+def test_conv16_splitk_finalizes_consumer_groupnorm(hip, B, Cin, Cout, H, k, film):
+    """Split-K launches can finalize the GroupNorm(+FiLM) that will consume their output in the reduction pass
+    (ddnm_conv16_desc::fin_*): same output tensor as the plain launch, and the affine equals what
+    ddnm_gn_finalize_tiles_f32 makes of the plain launch's partials (fp64 combination in another fixed order: <= 1e-6)
+    and F.group_norm of the rounded output."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, H, H, generator=g).half()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (k * k * Cin) ** -0.5).half()
+    bias = torch.randn(Cout, generator=g).cuda()
+    r = nhwc16(torch.randn(B, Cout, H, H, generator=g))
+    gamma, beta = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(), (0.1 * torch.randn(Cout, generator=g)).cuda()
+    fl = torch.randn(B, 2 * Cout + 40, generator=g).cuda() if film else None
+    fs = 2 * Cout + 40
+    w16 = ops.pack_conv_weight16(w.cuda())
+    plain = ops.conv16(nhwc16(x), w16, Cout, k, bias=bias, res=r)
+    ws0 = ops.GroupNormWorkspace("cuda", B, Cout, 16)
+    sc0, sh0 = ops.group_norm_affine(plain, None, gamma, beta, 1e-5, ws0, film=fl, film_stride=fs if film else 0)
+    sc0, sh0 = sc0[:B * Cout].clone(), sh0[:B * Cout].clone()
+    ws1 = ops.GroupNormWorkspace("cuda", B, Cout, 16)
+    fused = ops.conv16(nhwc16(x), w16, Cout, k, bias=bias, res=r, fin=("gn", gamma, beta, fl, fs if film else 0, 1e-5, ws1))
+    torch.cuda.synchronize()
+    assert fused.gn is not None and fused.gn[2] == "gn", "this shape must take the finalizing reduction"
+    assert torch.equal(fused.t, plain.t)
+    sc1, sh1 = fused.gn[0][:B * Cout], fused.gn[1][:B * Cout]
+    assert rel(sc1, sc0) < 1e-6 and rel(sh1, sh0) < 1e-6
+    assert fused.tiles == 1
+    # its one-tile partials serve any other consumer (e.g. a later skip concat)
+    sc2, sh2 = ops.group_norm_affine(fused, None, gamma, beta, 1e-5, ops.GroupNormWorkspace("cuda", B, Cout, 16),
+                                     film=fl, film_stride=fs if film else 0)
+    assert rel(sc2[:B * Cout], sc0) < 1e-6 and rel(sh2[:B * Cout], sh0) < 1e-6
+    got = fused.t.float().cpu().permute(0, 3, 1, 2)
+    want = F.group_norm(got, 32, gamma.cpu(), beta.cpu(), eps=1e-5)
+    if film:
+        s_, t_ = fl.cpu()[:, :Cout], fl.cpu()[:, Cout:2 * Cout]
+        want = want * (1 + s_[:, :, None, None]) + t_[:, :, None, None]
+    sc, sh = sc1.reshape(B, Cout).cpu(), sh1.reshape(B, Cout).cpu()
+    assert rel(got * sc[:, :, None, None] + sh[:, :, None, None], want) < 2e-5
+
+
+def test_conv16_unsplit_launch_ignores_fin(hip):
+    """A launch that is not split (enough tiles for the chip) does not finalize: the caller falls back to the finalize
+    kernel (Act.gn is None) and the partials keep their per-tile layout."""
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 256, 64, 64, generator=g)
+    w = torch.randn(256, 256, 3, 3, generator=g) * 0.02
+    gamma, beta = torch.ones(256).cuda(), torch.zeros(256).cuda()
+    ws = ops.GroupNormWorkspace("cuda", 2, 256, 16)
+    out = ops.conv16(nhwc16(x), ops.pack_conv_weight16(w.cuda()), 256, 3, fin=("gn", gamma, beta, None, 0, 1e-5, ws))
+    assert out.gn is None and out.tiles > 1
