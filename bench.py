@@ -138,7 +138,9 @@ def cpu_baseline(cfg, sd, budget_s=90.0):
 
 # ------------------------------------------------------------------------------------------------- ImageNet workloads
 ADM_FLOPS_PER_FWD = 2242.87e9          # SURVEY.md section 8(d), per image
-ADM_CC_FLOPS_PER_STEP = 2243.9e9 + 300e9      # class-conditional UNet + classifier forward / input-gradient (estimate)
+ADM_CC_FLOPS_PER_FWD = 2243.9e9        # class-conditional UNet (+ label embedding)
+CLS_FLOPS_ESTIMATE = 300e9             # classifier forward + input gradient per image: SURVEY's estimate, replaced by the
+#                                        count of the engine's own launches (convolutions + batched GEMMs) when available
 PEAK_F16_TFLOPS = 2500.0               # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 ADM_WORKLOADS = {
     "c3": dict(desc="imagenet_256.yml colorization, T_sampling=100 (BASELINE configs[2]: batch_size=32 sharded across "
@@ -184,6 +186,7 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
     model.load_state_dict(model.random_state_dict(1234))
     model.convert_to_fp16()
     cls_fn = None
+    cls_flops_per_image = None
     if name == "c5":
         kw = classifier_defaults()
         kw["image_size"] = 256
@@ -196,6 +199,16 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
                              for k, v in clf.state_dict_shapes().items()})
         clf.convert_to_fp16()                  # imagenet_256_cc.yml: classifier_use_fp16 true
         cls_fn = make_cond_fn(clf, 1.0)
+        try:        # FLOPs of one guidance evaluation, counted from the launches of one instrumented call
+            ctimer = ops.KernelTimer()
+            ops.set_kernel_timer(ctimer)
+            xx = torch.randn(2, 3, 256, 256, device=dev)
+            cls_fn(xx, torch.full((2,), 500.0, device=dev), torch.full((2,), 951, dtype=torch.long, device=dev))
+            ops.set_kernel_timer(None)
+            torch.cuda.synchronize()
+            cls_flops_per_image = sum(f for _, f, _, _ in ctimer.records) / 2.0
+        except Exception:      # noqa: BLE001
+            ops.set_kernel_timer(None)
     betas = torch.from_numpy(get_beta_schedule("linear", beta_start=1e-4, beta_end=0.02,
                                                num_diffusion_timesteps=1000)).float().to(dev)
     if strong:
@@ -234,7 +247,9 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
     dt_rank = time.perf_counter() - t0
     dt, dt_min = ddist.reduce_scalar(dt_rank, dev, "max"), ddist.reduce_scalar(dt_rank, dev, "min")
     value = steps * n_total / dt
-    per_step = ADM_CC_FLOPS_PER_STEP if name == "c5" else ADM_FLOPS_PER_FWD
+    per_step = ADM_FLOPS_PER_FWD
+    if name == "c5":
+        per_step = ADM_CC_FLOPS_PER_FWD + (cls_flops_per_image or CLS_FLOPS_ESTIMATE)
     tfl = value * nfe * per_step / 1e12 / world
     res = {"value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 2), "ms_per_step_rank_min": round(dt_min / steps * 1e3, 2),
@@ -244,6 +259,12 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
            "config": {"workload": W["desc"], "global_batch": n_total, "per_gpu_batch": B, "nfe_per_image": nfe},
            "whole_loop_tflops_per_gpu": round(tfl, 1), "whole_loop_frac": round(tfl / PEAK_F16_TFLOPS, 4),
            "finite": bool(torch.isfinite(out).all())}
+    if name == "c5":
+        res["classifier_gflop_per_image_step"] = round((cls_flops_per_image or CLS_FLOPS_ESTIMATE) / 1e9, 1)
+        res["classifier_flops_source"] = ("counted from the launches of one guidance evaluation (convolutions, batched "
+                                          "GEMMs; GroupNorm / softmax / pooling not counted)" if cls_flops_per_image
+                                          else "SURVEY estimate")
+        res["guidance_stream"] = "second HIP stream, one reverse step ahead (DDNM_CLS_OVERLAP=0: serial)"
     if roofline and rank == 0 and B > 0:
         try:
             timer = ops.KernelTimer()

@@ -674,19 +674,21 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const 
 // Thread = one float4 channel column x one pixel row of 256 / (CS/4); fp32 partials per thread, fp64 combination in a
 // fixed order (no atomics: repeated launches are bit-identical).
 // =====================================================================================
-static __global__ __launch_bounds__(256) void conv16_splitk_reduce_fin_kernel(const Conv16Args p, int CS) {
-    __shared__ f32x4 red[2][256];
+constexpr int C16_FIN_THREADS = 1024;
+static __global__ __launch_bounds__(C16_FIN_THREADS) void conv16_splitk_reduce_fin_kernel(const Conv16Args p, int CS) {
+    __shared__ f32x4 red[2][C16_FIN_THREADS];
     __shared__ double chan[2][64];
     __shared__ float mr[2][16];
     const ddnm_conv16_desc& d = p.d;
     const int b = blockIdx.x, cb = blockIdx.y * CS;
-    const int c4n = CS >> 2, rows = 256 / c4n;
+    const int c4n = CS >> 2, rows = C16_FIN_THREADS / c4n;
     const int hw = d.H * d.W;
     const size_t slab = (size_t)p.M * d.Cout;
     const int tid = threadIdx.x;
     const int c4 = tid % c4n, prow = tid / c4n, n = cb + c4 * 4;
-    const _Float16* res = reinterpret_cast<const _Float16*>(d.res);
-    _Float16* out = reinterpret_cast<_Float16*>(d.out);
+    const float* __restrict__ wsp = d.workspace;
+    const _Float16* __restrict__ res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* __restrict__ out = reinterpret_cast<_Float16*>(d.out);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     f32x4 add = {0.f, 0.f, 0.f, 0.f};
     if (d.bias) add = *reinterpret_cast<const f32x4*>(d.bias + n);
@@ -700,37 +702,71 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_fin_kernel(co
             f_t = d.fin_film[(size_t)b * d.fin_film_stride + d.Cout + cb + tid];
         }
     }
-    for (int pp = prow; pp < hw; pp += rows) {
-        const size_t o = ((size_t)b * hw + pp) * d.Cout + n;
-        f32x4 v = *reinterpret_cast<const f32x4*>(d.workspace + o);
-#pragma unroll 4
-        for (int k = 1; k < p.ksplit; ++k) v = v + *reinterpret_cast<const f32x4*>(d.workspace + o + k * slab);
-        v = v + add;
-        if (res) {
-            size_t ro = o;
-            if (d.res_ups) {
-                const int oy = pp / d.W, ox = pp - oy * d.W;
-                ro = (((size_t)b * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1)) * d.Cout + n;
-            }
-            const half4 r4 = *reinterpret_cast<const half4*>(res + ro);
-            v = v + f32x4{(float)r4.x, (float)r4.y, (float)r4.z, (float)r4.w};
+    // The pass is a latency chain unless many loads fly at once: 4 pixels per trip, every slab / residual load of the
+    // trip issued before the first use (the loop as written per pixel ran at one HBM round trip per iteration).
+    constexpr int PB = 4;
+    for (int p0 = prow; p0 < hw; p0 += rows * PB) {
+        f32x4 v[PB];
+        half4 r4[PB];
+        size_t o[PB];
+        bool ok[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int pp = p0 + u * rows;
+            ok[u] = pp < hw;
+            o[u] = ((size_t)b * hw + (ok[u] ? pp : 0)) * d.Cout + n;
+            v[u] = *reinterpret_cast<const f32x4*>(wsp + o[u]);
         }
-        const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        *reinterpret_cast<half4*>(out + o) = h;
-        const f32x4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
-        s += f;
-        ss += f * f;
+        for (int k = 1; k < p.ksplit; ++k) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) v[u] = v[u] + *reinterpret_cast<const f32x4*>(wsp + o[u] + k * slab);
+        }
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                size_t ro = o[u];
+                if (d.res_ups) {
+                    const int pp = ok[u] ? p0 + u * rows : 0;
+                    const int oy = pp / d.W, ox = pp - oy * d.W;
+                    ro = (((size_t)b * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1)) * d.Cout + n;
+                }
+                r4[u] = *reinterpret_cast<const half4*>(res + ro);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            if (!ok[u]) continue;
+            f32x4 t = v[u] + add;
+            if (res) t = t + f32x4{(float)r4[u].x, (float)r4[u].y, (float)r4[u].z, (float)r4[u].w};
+            const half4 h = {(_Float16)t.x, (_Float16)t.y, (_Float16)t.z, (_Float16)t.w};
+            *reinterpret_cast<half4*>(out + o[u]) = h;
+            const f32x4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+            s += f;
+            ss += f * f;
+        }
     }
     red[0][tid] = s;
     red[1][tid] = ss;
     __syncthreads();
-    if (tid < CS) {                                  // channel cb + tid: its column's pixel rows, in order
-        const int col = tid >> 2, e = tid & 3;
+    // per-channel totals over the pixel rows, fixed order: 8 threads per channel take every 8th row (fp64), then the
+    // 8 partial sums are added in order (a single thread per channel walked up to 256 LDS rows: 4 us of the kernel)
+    __shared__ double part[2][64][8];
+    if (tid < CS * 8) {
+        const int ch = tid >> 3, seg = tid & 7;
+        const int col = ch >> 2, e = ch & 3;
         double a = 0.0, q = 0.0;
-        for (int r = 0; r < rows; ++r) {
+        for (int r = seg; r < rows; r += 8) {
             a += (double)red[0][r * c4n + col][e];
             q += (double)red[1][r * c4n + col][e];
         }
+        part[0][ch][seg] = a;
+        part[1][ch][seg] = q;
+    }
+    __syncthreads();
+    if (tid < CS) {
+        double a = 0.0, q = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += part[0][tid][k]; q += part[1][tid][k]; }
         chan[0][tid] = a;
         chan[1][tid] = q;
         if (d.stats_out)                             // one tile per image: other consumers (skip concats) finalize from it
@@ -740,7 +776,7 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_fin_kernel(co
     const int cpg = d.Cout / d.fin_groups, ng = CS / cpg;
     if (tid < ng) {
         double a = 0.0, q = 0.0;
-        for (int j = 0; j < cpg; ++j) { a += chan[0][tid * cpg + j]; q += chan[1][tid * cpg + j]; }
+        for (int j = 0; j < cpg; ++j) { a += chan[0][tid * cpg + j]; q += chan[1][tid * cpg + j]; }     // cpg <= 64
         const double cnt = (double)hw * (double)cpg;
         const double mean = a / cnt;
         double var = q / cnt - mean * mean;
@@ -962,7 +998,7 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
         else { DDNM_LAUNCH((conv16_kernel<1, 1, 4>), grid, dim3(512), 0, s, p); }
     }
     if (pl.fin_cs > 0) {
-        DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel, dim3(d->B, d->Cout / pl.fin_cs), dim3(256), 0, s, p, pl.fin_cs);
+        DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel, dim3(d->B, d->Cout / pl.fin_cs), dim3(C16_FIN_THREADS), 0, s, p, pl.fin_cs);
     } else if (pl.ksplit > 1) {
         const int tpi = pl.stats_tiles;
         DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 255) / 256), dim3(256), 0, s, p, tpi);

@@ -522,6 +522,14 @@ def bgemm(A, Bm, C, M, N, K, *, lda, ldb, ldc, transb, batch=1, inner=1, sA=(0, 
     d.transb, d.batch, d.inner = int(transb), batch, inner
     d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi, d.sDo, d.sDi = sA[0], sA[1], sB[0], sB[1], sC[0], sC[1], sD[0], sD[1]
     d.alpha, d.beta, d.transa = alpha, beta, int(transa)
+    if _timer is not None:           # FLOP accounting of an instrumented pass (bench.py counts the classifier's work)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().ddnm_bgemm_f32(ctypes.byref(d), _stream()), "ddnm_bgemm_f32")
+        e1.record()
+        _timer.records.append(("bgemm_f32", 2.0 * M * N * K * batch, e0, e1))
+        _timer.shapes.append((batch, M, N, K, 0, 1, 1, 0, 0, False, False))
+        return C
     check(_lib.lib().ddnm_bgemm_f32(ctypes.byref(d), _stream()), "ddnm_bgemm_f32")
     return C
 

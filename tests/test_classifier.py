@@ -180,3 +180,39 @@ def test_guided_sampler_small(hip):
                            cls_fn=make_cond_fn(clf, 1.0), classes=None, config=cfg, noise=[n.cuda() for n in tape])
     torch.cuda.synchronize()
     assert rel(xs[0], xt) < 2e-4
+
+
+@pytest.mark.gpu
+def test_guidance_stream_equals_serial_order(hip, monkeypatch):
+    """The guidance term is evaluated on the initial noise (svd_ddnm.py:49-52), so the engine runs it on a second HIP
+    stream one reverse step ahead of the UNet (ddnm_amd/functions/svd_ddnm.py::_GuidanceAhead).  Same launches, same
+    inputs: the restored images are bit-identical to the serial order (DDNM_CLS_OVERLAP=0), with time travel (the
+    schedule revisits timesteps) and through DDNM+ as well."""
+    from ddnm_amd.functions.svd_ddnm import ddnm_diffusion, ddnm_plus_diffusion
+    from ddnm_amd.guided_diffusion.classifier import make_cond_fn
+    from ddnm_amd.guided_diffusion.unet import create_model
+    from oracle import schedule
+    from tests.helpers import engine_operator
+    cfg, sd = cases.adm_net("small")
+    cc = weights.classifier_config(**KINDS["small"])
+    clf = _engine(cc, weights.classifier_state_dict(cc))
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 8, 2, 2
+    n_it = len(schedule.jump_times(8, 2, 2)) - 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 3, n_it)
+    op = engine_operator("colorization", 32)
+    y = cases.make_operator("colorization", 32).A(x_orig).cuda()
+    model = create_model(**vars(cfg.model))
+    model.load_state_dict(sd)
+    outs = {}
+    for mode in ("1", "0", "1"):
+        monkeypatch.setenv("DDNM_CLS_OVERLAP", mode)
+        xs, x0s = ddnm_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, cls_fn=make_cond_fn(clf, 2.0),
+                                 classes=None, config=cfg, noise=[n.cuda() for n in tape], return_cpu=False)
+        xp, _ = ddnm_plus_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, 0.1, cls_fn=make_cond_fn(clf, 2.0),
+                                    classes=None, config=cfg, noise=[n.cuda() for n in tape], return_cpu=False)
+        torch.cuda.synchronize()
+        outs.setdefault(mode, []).append((xs[0].clone(), x0s[0].clone(), xp[0].clone()))
+    a, b, c = outs["1"][0], outs["0"][0], outs["1"][1]
+    for u, v, w in zip(a, b, c):
+        assert bool(torch.isfinite(u).all())
+        assert torch.equal(u, v) and torch.equal(u, w)

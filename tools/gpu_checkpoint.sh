@@ -1,9 +1,12 @@
 #!/bin/bash
 # Round checkpoint on an MI355X box (run through gpurun from the repo root):
-#   smoke, full GPU test suite, rocprofv3 kernel traces of the bench command and of the ADM fp16 forward, the PMC passes
-#   (separate runs) over the celeba forward (fp32 headline kernel) and the ADM forward (conv16), and LAST the headline
-#   bench line (with the c3 / c4 / c5 workloads); summaries land in gpurun_out/ and are copied into profiles/ by hand.
+#   smoke, full GPU test suite, rocprofv3 kernel traces of the bench command and of the ADM fp16 forward (forwards only:
+#   tools/adm_fwd.py / tools/forward_once.py launch a marker kernel after set-up and warm-up, the summaries cut there),
+#   the PMC passes (separate runs) over the celeba forward (fp32 headline kernel) and the ADM forward (conv16), and LAST
+#   the headline bench line (with the c3 / c4 / c5 workloads); summaries land in gpurun_out/ and the PMC json files are
+#   installed into profiles/ before the bench line is taken (bench.py binds them by source digest).
 # Every step runs under its own `timeout`: a faulting GPU once left rocprofv3 hanging for the whole remaining budget.
+R=${ROUND:-r03}
 set +e
 python - <<'PY' || { echo 'GPU sanity check failed: not running the checkpoint on this box'; exit 3; }
 import torch
@@ -14,9 +17,9 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tail -5 gpurun_out/smoke.log; echo 'smoke() failed: stopping before the long steps'; exit 4; }
 tail -1 gpurun_out/smoke.log
-if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6; fi
+if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee gpurun_out/${R}_gpu_tests.log; fi
 cd /tmp
-rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/prof_adm16 /root/repo/gpurun_out/pmc_c2 /root/repo/gpurun_out/pmc16
+rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/prof_adm16 /root/repo/gpurun_out/prof_c2fwd /root/repo/gpurun_out/pmc_c2 /root/repo/gpurun_out/pmc16
 timeout -k 10 420 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-workloads > /root/repo/gpurun_out/prof_bench.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_adm16 -o adm -- python /root/repo/tools/adm_fwd.py 5 > /root/repo/gpurun_out/prof_adm16.log 2>&1
 for k in mfma fetch write; do
@@ -25,11 +28,13 @@ for k in mfma fetch write; do
   timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d /root/repo/gpurun_out/pmc16/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16_$k.log 2>&1
 done
 cd /root/repo
-python tools/prof_summary.py $(find gpurun_out/prof_bench -name "*.db" | head -1) gpurun_out/prof_bench_summary.md > /dev/null; head -12 gpurun_out/prof_bench_summary.md
-python tools/prof_summary.py $(find gpurun_out/prof_adm16 -name "*.db" | head -1) gpurun_out/prof_adm16_summary.md > /dev/null; head -14 gpurun_out/prof_adm16_summary.md
-python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/pmc_c2_dominant.json gpurun_out/pmc_c2_dominant.md $(find gpurun_out/prof_bench -name "*.db" | head -1) | tail -8
-PMC_KERNEL="conv16_kernel<9, 4, 4>" PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/pmc16_conv16.json gpurun_out/pmc16_conv16.md $(find gpurun_out/prof_adm16 -name "*.db" | head -1) | tail -8
+BDB=$(find gpurun_out/prof_bench -name "*.db" | head -1); ADB=$(find gpurun_out/prof_adm16 -name "*.db" | head -1)
+python tools/prof_summary.py $BDB gpurun_out/${R}_bench_kernel_stats.md > /dev/null; head -12 gpurun_out/${R}_bench_kernel_stats.md
+python tools/prof_summary.py $ADB gpurun_out/${R}_adm_fp16_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_adm_fp16_forward_kernel_stats.md
+python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
+PMC_AFTER_MARKER=finalize_psnr python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
 # bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
-# (profiles/*_pmc_dominant_kernel.json): install this run's summaries first, then take the bench line
-cp gpurun_out/pmc_c2_dominant.json profiles/r02_pmc_dominant_kernel.json; cp gpurun_out/pmc_c2_dominant.md profiles/r02_pmc_dominant_kernel.md
-timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/bench_line.json
+# (profiles/*_pmc_dominant_kernel.json, profiles/*_adm_pmc_conv16.json): install this run's summaries first
+cp gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md profiles/
+timeout 1200 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/${R}_bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/${R}_bench_line.json
