@@ -76,30 +76,34 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* _
     }
 }
 
-// coef[b][g] = (P1/cnt, rstd^2 * P2/cnt).  One workgroup per sample: 8 threads per group walk the chunk partials
-// with stride 8 (a single thread per group chained hundreds of dependent 16-byte loads: 13 us per launch), combined
-// through LDS in a fixed order.
-__global__ __launch_bounds__(512) void gn_bwd_finalize_kernel(const double* __restrict__ partial, int nchunk,
+// coef[b][g] = (P1/cnt, rstd^2 * P2/cnt).  One workgroup per (sample, group): 256 threads stride over the chunk partials
+// (up to 256 of them at 256^2), fp64 xor-butterfly inside each wave, the four wave sums added in order -- fixed
+// shape, deterministic.  (One workgroup per SAMPLE with 8 threads per group took 13 us per launch: 46 launches per
+// guidance evaluation.)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ partial, int nchunk,
                                                               const float* __restrict__ mean_rstd, int HW, int C, int groups,
                                                               float* __restrict__ coef) {
-    __shared__ double red[8][64][2];
-    const int b = blockIdx.x, g = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    __shared__ double red[4][2];
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const float rstd_f = mean_rstd[((size_t)b * groups + g) * 2 + 1];
     double a1 = 0.0, a2 = 0.0;
-    if (g < groups) {
-        for (int ch = sl; ch < nchunk; ch += 8) {
-            const double* p = partial + (((size_t)b * nchunk + ch) * groups + g) * 2;
-            a1 += p[0];
-            a2 += p[1];
-        }
+    for (int ch = tid; ch < nchunk; ch += 256) {
+        const double* p = partial + (((size_t)b * nchunk + ch) * groups + g) * 2;
+        a1 += p[0];
+        a2 += p[1];
     }
-    red[sl][g][0] = a1;
-    red[sl][g][1] = a2;
-    __syncthreads();
-    if (sl != 0 || g >= groups) return;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) { a1 += red[k][g][0]; a2 += red[k][g][1]; }
+    for (int o = 32; o > 0; o >>= 1) {
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = a1; red[tid >> 6][1] = a2; }
+    __syncthreads();
+    if (tid != 0) return;
+    a1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    a2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     const double cnt = (double)HW * (double)(C / groups);
-    const double rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
+    const double rstd = (double)rstd_f;
     coef[((size_t)b * groups + g) * 2 + 0] = (float)(a1 / cnt);
     coef[((size_t)b * groups + g) * 2 + 1] = (float)(rstd * rstd * a2 / cnt);
 }
@@ -159,7 +163,7 @@ extern "C" int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, 
     hipStream_t s = (hipStream_t)stream;
     DDNM_LAUNCH(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), s, x, dA, dA_ups, gn_scale,
                 gn_shift, mean_rstd, silu, H, W, C, groups, partial, nchunk, pix);
-    DDNM_LAUNCH(gn_bwd_finalize_kernel, dim3(B), dim3(512), 0, s, partial, nchunk, mean_rstd, HW, C, groups, coef);
+    DDNM_LAUNCH(gn_bwd_finalize_kernel, dim3(B, groups), dim3(256), 0, s, partial, nchunk, mean_rstd, HW, C, groups, coef);
     const size_t total4 = (size_t)B * HW * C4;
     DDNM_LAUNCH(gn_bwd_apply_kernel, GRID_1D(total4), dim3(256), 0, s, x, dA, dA_ups, gn_scale, gn_shift, mean_rstd,
                 coef, silu, add, add_ups, H, W, C, groups, dx, total4);

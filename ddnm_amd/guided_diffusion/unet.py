@@ -415,7 +415,8 @@ class UNetModel:
         ups = kw.get("ups", False)
         Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
         if ops.conv16_supported(B, Ho, Wo, cin, cout, 3, ups=ups):
-            if os.environ.get("DDNM_H16_PREPASS") == "1":
+            pre = os.environ.get("DDNM_H16_PREPASS", "")
+            if pre == "1" or (pre.startswith("auto") and gn is not None and cout >= int(pre[4:] or 1024) and Ho * Wo <= 1024):
                 a = x0.t if (gn is None and x1 is None) else ops.gn_apply16(x0, x1, gn, silu)
                 return ops.conv16(a, w16, cout, 3, **kw)
             return ops.conv16(x0, w16, cout, 3, src1=x1, gn=gn, gn_silu=silu, **kw)

@@ -105,6 +105,22 @@ for name, Cin, Cout, H, k, res in {"low": LOW, "one": ONE, "mid": MID}.get(os.en
         if len(wcopies) > 1:
             flush.zero_()               # evict the freshly cloned weights from L2 / MALL
         torch.cuda.synchronize()
+        if os.environ.get("PREF") == "1":
+            # weight-prefetch experiment: an unrelated kernel READS the (cold) weight copy right before the convolution
+            # that uses it (HBM -> MALL / some L2s); only the convolutions are timed
+            tot = 0.0
+            for it in range(10):
+                wc = wcopies[it % len(wcopies)]
+                d.weight = wc.data_ptr()
+                _ = wc.view(torch.int16).sum()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.ddnm_conv16(ctypes.byref(d), stream)
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            row.append(tot / 10 * 1e3)
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for it in range(10):
