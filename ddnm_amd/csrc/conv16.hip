@@ -21,6 +21,7 @@
 // next tap is requested right after the barrier that frees its buffer -- one barrier per 32 MFMAs per wave.
 // 1x1 convolutions / the im2col'ed 8x8 level run the same loop with one tap and a flat row mapping.
 #include "conv_common.h"
+#include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
