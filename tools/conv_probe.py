@@ -121,7 +121,7 @@ def main():
         d.out = out.data_ptr()
         d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, Hin, Hin, C0, C1, Cout
         d.ksize, d.stride, d.pad, d.Ho, d.Wo = k, stride, (0 if stride == 2 else k // 2), Ho, Ho
-        d.ups, d.gn_silu, d.out_nchw, d.badd_stride, d.tile = ups, 1, 0, 0, tile
+        d.ups, d.gn_silu, d.out_nchw, d.badd_stride, d.tile = ups, 1, 0, 0, (int(os.environ.get('TILE', '0')) if (k == 3 and stride == 1 and Cout % 128 == 0) else tile)
         d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
         flops = 2.0 * B * Ho * Ho * Cout * k * k * (C0 + C1)
         row = []
