@@ -12,7 +12,10 @@ Synthetic inputs, seeded random weights of the real architecture (no checkpoints
 
 N>1: one process per GPU, every rank restores its own batch of 8 (weak scaling), one RCCL
 all_gather of the restored images at the end of each step (inside the timed region).
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Started WITHOUT torchrun, `--gpus N > 1` re-executes itself under
+`torch.distributed.run --nproc-per-node N` (exit code 2 when fewer than N devices are visible); the line
+carries `backend`, `ranks_seen` and the per-rank step-time spread, and at N > 1 it appends configs[2] /
+configs[3] with their fixed GLOBAL batch split over the ranks (`--no-extra-workloads` skips them).
 
 At 1 GPU the default run appends `"workloads": {"c3", "c4", "c5"}`: the per-GPU shards of BASELINE configs[2..4]
 (ImageNet ADM UNet in the runner's fp16 mode), 1 warm-up + 2 timed restorations each, each with its own
@@ -502,6 +505,20 @@ def main():
         del model
         torch.cuda.empty_cache()
         line["workloads"] = {}
+        done = None
+        if world > 1:
+            # insurance for the headline line of a multi-rank run: if a collective of the appended workloads hangs, rank 0
+            # still prints the line (workloads marked unmeasured) and every rank leaves
+            import threading
+            done = threading.Event()
+
+            def watchdog(limit=float(os.environ.get("DDNM_BENCH_EXTRA_TIMEOUT", "900"))):
+                if not done.wait(limit + (0 if rank == 0 else 30)):
+                    if rank == 0:
+                        line["workloads"] = {"error": f"appended workloads did not finish within {limit:.0f} s: unmeasured"}
+                        print(json.dumps(line), flush=True)
+                    os._exit(0 if rank == 0 else 1)
+            threading.Thread(target=watchdog, daemon=True).start()
         if world == 1:
             # BASELINE configs[2..4] on this GPU (their per-GPU shards), short: 1 warm-up + 2 timed restorations each
             plan = [("c3", False, 2), ("c4", False, 2), ("c5", False, 2)]
@@ -515,6 +532,8 @@ def main():
                                                         roofline=not args.no_roofline, lib_digest=lib_digest)
             except Exception as e:    # noqa: BLE001
                 line["workloads"][wname] = {"error": repr(e)}
+        if done is not None:
+            done.set()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
