@@ -24,7 +24,7 @@ VARIANTS = {"base": [], "no_epi": ["-DDDNM_P16_NO_EPI"], "no_main": ["-DDDNM_P16
             "ne_all3": ["-DDDNM_P16_NO_EPI", "-DDDNM_P16_NO_FRAG", "-DDDNM_P16_NO_SYNC", "-DDDNM_P16_NO_WLOAD"],
             "burst": ["-DDDNM_P16_ILV=0"], "early": ["-DDDNM_P16_LATE_DMA=0"], "late_res": ["-DDDNM_P16_EARLY_RES=0"], "old": None, "maxm0": ["-DDDNM_P16_WMAJOR_MAXM=0"], "maxm16": ["-DDDNM_P16_WMAJOR_MAXM=16"],
             "maxm64": ["-DDDNM_P16_WMAJOR_MAXM=64"],
-            "mt1off": ["-DDDNM_P16_MT1=0"], "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
+            "mt1off": ["-DDDNM_P16_MT1=0"], "nowl": ["-DDDNM_P16_NO_WLOAD"], "nosync": ["-DDDNM_P16_NO_SYNC"], "nofrag": ["-DDDNM_P16_NO_FRAG"], "ks1": ["-DDDNM_P16_KSCAP=1"], "ks2": ["-DDDNM_P16_KSCAP=2"], "ks4": ["-DDDNM_P16_KSCAP=4"]}
 if os.environ.get("ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ONLY"].split(",")}
 extra = [a for a in sys.argv[1:] if a.startswith("-D")]
