@@ -29,6 +29,7 @@ class ConvDesc(Structure):
         ("stats_out", c_void_p),
         ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
         ("SC0", c_int32), ("SC1", c_int32),
+        ("acc_scale", c_float), ("reserved0", c_int32),
     ]
 
 
@@ -103,6 +104,11 @@ PROTOTYPES = {
     "ddnm_conv3x3_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv3x3_s16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv3x3_s16_supported": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv3x3_s16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
+    "ddnm_conv3x3_s16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv3x3_s16_act_scale": (c_float, []),
     "ddnm_conv16": (c_int32, [POINTER(Conv16Desc), c_void_p]),
     "ddnm_conv16_supported": (c_int32, [POINTER(Conv16Desc)]),
     "ddnm_conv16_fuses_fin": (c_int32, [POINTER(Conv16Desc)]),
@@ -192,7 +198,7 @@ class DDNMHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def lib():

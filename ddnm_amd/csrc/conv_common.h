@@ -54,7 +54,7 @@ __device__ __forceinline__ TileMap make_tilemap(const ConvArgs& p, int m_tile) {
 // ---- shared epilogue.  C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
 template <int WM, int WN, int MT, int NT, bool RES_ALL_UPFRONT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& tm, int n_tile, int m_tile, int slice,
-                                              f32x16 (&acc)[MT][NT], float* lds) {
+                                              f32x16 (&acc)[MT][NT], float* lds, const float acc_scale = 1.f) {
     constexpr int BN = WN * NT * 32;
     const ddnm_conv_desc& d = p.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = acc[i][j][r] + add + rv[i][j][r];
+                    const float v = acc[i][j][r] * acc_scale + add + rv[i][j][r];
                     if (partial) ws[o[i][j][r]] = v;
                     else out[o[i][j][r]] = v;
                     cs[j] += v;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[i][j][r] + add + rv[r];
+                const float v = acc[i][j][r] * acc_scale + add + rv[r];
 #ifdef DDNM_PROBE_NO_STORE            // timing probe: everything but the global stores (wrong results)
                 if (v == 12345.678f)
 #endif

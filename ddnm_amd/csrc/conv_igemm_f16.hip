@@ -30,16 +30,40 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 constexpr int KC16 = DDNM_F16_KC;   // channels per chunk
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 
+// fp32 x4 -> hi | lo fp16 halves of a split row: hi at dst, lo 32 halfs behind it (conv3x3_halo_f16_kernel<.., SPLIT>)
+#ifndef DDNM_S16_ASCALE
+#define DDNM_S16_ASCALE 1.0f        // power-of-two pre-scale of the activation operand (undone by acc_scale)
+#endif
+__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {
+    v = v * DDNM_S16_ASCALE;
+    const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const half4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
+                     (_Float16)(v.w - (float)h.w)};
+    *reinterpret_cast<half4*>(dst) = h;
+    *reinterpret_cast<half4*>(dst + 32) = l;
+}
+
 // SRC16 = the activation operand is already fp16 in HBM (written by ddnm_gn_apply_f16: GroupNorm affine +
 // swish applied ONCE per element instead of once per (output-channel tile x halo overlap) inside this kernel,
 // where the v_exp/v_rcp work of a 1024-output-channel layer is repeated 10x and costs 25 % of the kernel).
-template <int WM, int WN, int MT, int NT, bool SRC16>
+//
+// SPLIT = fp32-grade products on the fp16 matrix pipe (the celeba `Model`, whose reference runs in fp32): every fp32
+// operand value v is carried as TWO fp16 numbers hi = rn16(v), lo = rn16(v - hi) (|v - hi - lo| <= 2^-22 |v|) and a
+// product is hi*hi' + hi*lo' + lo*hi' -- three MFMAs whose fp16 x fp16 products are exact in the fp32 accumulator;
+// the dropped lo*lo' term is 2^-22 relative.  A chunk is then 32 channels: an LDS row holds [hi 32 | lo 32] halfs,
+// i.e. the same 128 + 16 bytes as a 64-channel fp16 row, the weights arrive packed the same way ([hi 32 | lo 32]
+// per (row, tap, chunk), pre-scaled by a power of two so that `lo` stays a normal fp16 number) and
+// ddnm_conv_desc::acc_scale undoes the scaling in the epilogue.
+template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
+    static_assert(!(SPLIT && SRC16), "the split form reads fp32 activations");
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int MAXH = BM == 512 ? 612 : (BM == 256 ? 340 : (BM == 128 ? 204 : 136));
+    constexpr int KCH = SPLIT ? KC16 / 2 : KC16;                  // CHANNELS per chunk (an LDS row is always KC16 halfs)
+    constexpr int WE = SPLIT ? 2 : 1;                             // weight halfs per channel
     constexpr int HVEC = SRC16 ? 8 : 4;                           // channels per 16-byte global load
-    constexpr int HCOLS = KC16 / HVEC;                            // loads per 64-channel halo row
+    constexpr int HCOLS = KCH / HVEC;                             // loads per halo row of one chunk
     constexpr int HROWS_PER_PASS = NTHREADS / HCOLS;
     constexpr int HR = (MAXH + HROWS_PER_PASS - 1) / HROWS_PER_PASS;
     constexpr int BCOLS = KC16 / 8;                               // 16-byte pieces per weight row of one chunk
@@ -75,9 +99,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     }
     // ---- weight loader mapping: thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
     const int c8 = tid % BCOLS, brow = tid / BCOLS;
-    const _Float16* wbase = reinterpret_cast<const _Float16*>(d.weight) + (size_t)(n_tile * BN + brow) * 9 * p.Cin + c8 * 8;
+    const _Float16* wbase = reinterpret_cast<const _Float16*>(d.weight) + (size_t)(n_tile * BN + brow) * 9 * p.Cin * WE + c8 * 8;
 
-    const int nchunks = p.Cin / KC16;
+    const int nchunks = p.Cin / KCH;
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
 
     uint4 h_st[HR];                                 // fp32 mode: 4 floats (bit-cast); fp16 mode: 8 halfs
@@ -91,7 +115,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 
     constexpr int HSPLIT = (HR + 1) / 2;            // row slots [0, HSPLIT) and [HSPLIT, HR) are loaded / staged separately
     auto prefetch_halo_part = [&](int chunk, int i0, int i1) {
-        const int cb = chunk * KC16;
+        const int cb = chunk * KCH;
         const char* src;
         int cs, coff;
         if (cb < d.C0) { src = reinterpret_cast<const char*>(d.src0); cs = d.C0; coff = cb; }
@@ -113,15 +137,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     };
     auto prefetch_halo = [&](int chunk) { prefetch_halo_part(chunk, 0, HR); };
     auto prefetch_b = [&](int chunk, int tap) {
-        const _Float16* wp = wbase + (size_t)tap * p.Cin + chunk * KC16;
+        const _Float16* wp = wbase + ((size_t)tap * p.Cin + chunk * KCH) * WE;
 #ifdef DDNM_PROBE16_NO_BLOAD
         if (chunk < 0) {
 #endif
         b_st0 = *reinterpret_cast<const uint4*>(wp);
-        if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin);
+        if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin * WE);
         if constexpr (BR == 4) {
-            b_st2 = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * BROWS_PER_PASS) * 9 * p.Cin);
-            b_st3 = *reinterpret_cast<const uint4*>(wp + (size_t)(3 * BROWS_PER_PASS) * 9 * p.Cin);
+            b_st2 = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * BROWS_PER_PASS) * 9 * p.Cin * WE);
+            b_st3 = *reinterpret_cast<const uint4*>(wp + (size_t)(3 * BROWS_PER_PASS) * 9 * p.Cin * WE);
         }
 #ifdef DDNM_PROBE16_NO_BLOAD
         }
@@ -139,8 +163,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                 } else {
                     f32x4 v = __builtin_bit_cast(f32x4, h_st[i]);
                     if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
-                    half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                    *reinterpret_cast<half4*>(dst) = h;
+                    if constexpr (SPLIT) {
+                        split_store(dst, v);
+                    } else {
+                        half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                        *reinterpret_cast<half4*>(dst) = h;
+                    }
                 }
             }
         }
@@ -176,6 +204,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int tap_off = (ky * HWd + kx) * LDH + hbuf * MAXH * LDH;
         const _Float16* bf = b_frag + buf * BN * LDH;
+        if constexpr (SPLIT) {
+            // [hi 32 | lo 32] rows: k-step ks reads the hi fragment at ks*16 and the lo fragment 32 halfs behind it;
+            // the three products of one (i, j) tile are spread over the loop so that no MFMA waits on its predecessor
+#pragma unroll
+            for (int ks = 0; ks < KC16 / 32; ++ks) {
+                half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    ah[i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16);
+                    al[i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16 + 32);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16);
+                    bl[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16 + 32);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KC16 / 16; ++ks) {
             half8 a[MT], b[NT];
@@ -246,12 +308,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     // raw input at the centre tap (see conv_igemm_f32.hip)
     if (d.skip0 != nullptr) {
         // split-K launches share the shortcut's chunks like the main ones (slice 0 alone would run 2-3x longer)
-        const int SCin = d.SC0 + d.SC1, nsk_all = SCin / KC16;
+        const int SCin = d.SC0 + d.SC1, nsk_all = SCin / KCH;
         const int s_begin = (int)((long)nsk_all * slice / p.ksplit), s_end = (int)((long)nsk_all * (slice + 1) / p.ksplit);
-        const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin + c8 * 8;
+        const _Float16* swbase = reinterpret_cast<const _Float16*>(d.skip_weight) + (size_t)(n_tile * BN + brow) * SCin * WE + c8 * 8;
         // the raw input is fp32: thread -> (float4 column sc of 16, interior pixels srow + 32*i), staged at the
         // pixel's halo position so that mfma_tap(4) (centre tap) reads it
-        constexpr int SCOLS = KC16 / 4;                            // float4 pieces per raw-input row of one chunk
+        constexpr int SCOLS = KCH / 4;                             // float4 pieces per raw-input row of one chunk
         constexpr int SR = BM * SCOLS / NTHREADS;
         const int sc = tid % SCOLS, srow = tid / SCOLS;
         int soff[SR], sdst[SR];
@@ -266,18 +328,18 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         }
         f32x4 s_st[SR];
         auto prefetch_skip = [&](int ch) {
-            const int cb = ch * KC16;
+            const int cb = ch * KCH;
             const float* src;
             int cs, coff;
             if (cb < d.SC0) { src = d.skip0; cs = d.SC0; coff = cb; }
             else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
 #pragma unroll
             for (int i = 0; i < SR; ++i) s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)soff[i] * cs + coff + sc * 4);
-            b_st0 = *reinterpret_cast<const uint4*>(swbase + cb);
-            if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(swbase + (size_t)BROWS_PER_PASS * SCin + cb);
+            b_st0 = *reinterpret_cast<const uint4*>(swbase + cb * WE);
+            if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(swbase + ((size_t)BROWS_PER_PASS * SCin + cb) * WE);
             if constexpr (BR == 4) {
-                b_st2 = *reinterpret_cast<const uint4*>(swbase + (size_t)(2 * BROWS_PER_PASS) * SCin + cb);
-                b_st3 = *reinterpret_cast<const uint4*>(swbase + (size_t)(3 * BROWS_PER_PASS) * SCin + cb);
+                b_st2 = *reinterpret_cast<const uint4*>(swbase + ((size_t)(2 * BROWS_PER_PASS) * SCin + cb) * WE);
+                b_st3 = *reinterpret_cast<const uint4*>(swbase + ((size_t)(3 * BROWS_PER_PASS) * SCin + cb) * WE);
             }
         };
         if (s_begin < s_end) prefetch_skip(s_begin);
@@ -286,8 +348,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #pragma unroll
             for (int i = 0; i < SR; ++i) {
                 const f32x4 v = s_st[i];
-                half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                *reinterpret_cast<half4*>(&Hs[sdst[i]]) = h;
+                if constexpr (SPLIT) {
+                    split_store(&Hs[sdst[i]], v);
+                } else {
+                    half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    *reinterpret_cast<half4*>(&Hs[sdst[i]]) = h;
+                }
             }
             stage_b(0);
             __syncthreads();
@@ -295,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             mfma_tap(4, 0);
         }
     }
-    conv_epilogue<WM, WN, MT, NT, (MT * NT <= 4)>(p, tm, n_tile, m_tile, slice, acc, stat_lds);
+    conv_epilogue<WM, WN, MT, NT, (MT * NT <= 4)>(p, tm, n_tile, m_tile, slice, acc, stat_lds, SPLIT ? d.acc_scale : 1.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -303,11 +369,12 @@ struct PlanF16 {
     int BM, TW, TW_log2, tiles_x, ksplit;
 };
 
-static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl) {
+// kch = channels per K chunk: KC16 for fp16 operands, KC16 / 2 for the split (hi | lo) form
+static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl, int kch = KC16) {
     const int HWo = d->Ho * d->Wo;
     const int Cin = d->C0 + d->C1;
     if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hin || d->Wo != d->Win) return false;
-    if (Cin % KC16 || d->C0 % KC16 || d->Cout % 128 || d->out_nchw) return false;
+    if (Cin % kch || d->C0 % kch || d->Cout % 128 || d->out_nchw) return false;
     pl->BM = DDNM_F16_BM;
     if (HWo % pl->BM) return false;
     int tw = 32;
@@ -318,7 +385,7 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl) {
     pl->tiles_x = d->Wo / tw;
     const long tiles = (long)d->B * (HWo / pl->BM) * (d->Cout / 128);
     int ks = 1;
-    const int nchunks = Cin / KC16;
+    const int nchunks = Cin / kch;
     if (tiles < 192) {
         ks = (int)((512 + tiles - 1) / tiles);
         if (ks > nchunks) ks = nchunks;
@@ -345,8 +412,10 @@ extern "C" int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d) {
     return pl.ksplit > 1 ? splitk_stats_tiles(d) : d->Ho * d->Wo / pl.BM;
 }
 
-extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
+static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
+    const int kch = split ? KC16 / 2 : KC16;
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
+    if (split && (d->src_f16 || !(d->acc_scale > 0.f))) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
@@ -354,9 +423,9 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     PlanF16 pl;
-    if (!plan_f16(d, &pl)) return DDNM_E_SHAPE;
+    if (!plan_f16(d, &pl, kch)) return DDNM_E_SHAPE;
     if (d->skip0) {
-        if (d->ups || !d->skip_weight || d->SC0 <= 0 || d->SC0 % KC16 || d->SC1 % KC16 || (d->SC1 > 0 && !d->skip1))
+        if (d->ups || !d->skip_weight || d->SC0 <= 0 || d->SC0 % kch || d->SC1 % kch || (d->SC1 > 0 && !d->skip1))
             return DDNM_E_SHAPE;
     }
     if (pl.ksplit > 1) {
@@ -388,9 +457,34 @@ extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
 #else
-    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
+    if (split) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>), grid, dim3(512), 0, s, p); }
+    else if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), grid, dim3(512), 0, s, p); }
 #endif
     if (pl.ksplit > 1) return launch_splitk_reduce(p, s);
     return 0;
+}
+
+extern "C" int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream) { return run_f16(d, stream, false); }
+
+// ---- split form: fp32 tensors, fp32-grade products as three fp16 MFMAs (see the kernel's header comment)
+extern "C" int ddnm_conv3x3_s16_f32(const ddnm_conv_desc* d, void* stream) { return run_f16(d, stream, true); }
+
+extern "C" float ddnm_conv3x3_s16_act_scale(void) { return DDNM_S16_ASCALE; }
+
+extern "C" int ddnm_conv3x3_s16_supported(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    return d && !d->src_f16 && plan_f16(d, &pl, KC16 / 2) ? 1 : 0;
+}
+
+extern "C" int64_t ddnm_conv3x3_s16_workspace_floats(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    if (!d || !plan_f16(d, &pl, KC16 / 2)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? (int64_t)pl.ksplit * d->B * d->Ho * d->Wo * d->Cout : 0;
+}
+
+extern "C" int ddnm_conv3x3_s16_stats_tiles(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    if (!d || !plan_f16(d, &pl, KC16 / 2)) return DDNM_E_SHAPE;
+    return pl.ksplit > 1 ? splitk_stats_tiles(d) : d->Ho * d->Wo / pl.BM;
 }

@@ -8,10 +8,15 @@ protocol `model(x[B,3,R,R], t[B]) -> eps[B,3,R,R]` (NCHW fp32).
 Inside, nothing is a torch op.  Activations live in HBM as NHWC fp32 and every
 layer is a launch of a hand-written HIP kernel (ddnm_amd/csrc):
 
-  * conv3x3 / conv1x1 / strided conv  -> implicit GEMM on v_mfma_f32_32x32x2_f32;
-    its A-tile loader folds in GroupNorm-affine + swish, nearest x2 upsampling and
-    the skip-connection concat (two source pointers); its epilogue folds in the
-    bias, the timestep-embedding projection and the residual add.
+  * conv3x3 / conv1x1 / strided conv  -> implicit GEMM; its A-tile loader folds in
+    GroupNorm-affine + swish, nearest x2 upsampling and the skip-connection concat
+    (two source pointers); its epilogue folds in the bias, the timestep-embedding
+    projection and the residual add.  The 3x3 / stride-1 layers (97 % of the FLOPs)
+    run fp32-GRADE products on the fp16 matrix pipe: every fp32 operand is carried
+    as hi + lo fp16 halves and a product is three v_mfma_f32_32x32x16_f16 with fp32
+    accumulation (ddnm_conv3x3_s16_f32; measured CLOSER to an fp64 evaluation than
+    the fp32 MFMA kernel, at 2.8x its speed); the rest (1x1, strided, 8x8 level)
+    and DDNM_CONV_F32=mfma32 use v_mfma_f32_32x32x2_f32.
   * GroupNorm                          -> statistics kernel only (one read of the
     tensor); the normalised tensor is never written.
   * attention (1 head, d=512)          -> fused qkv 1x1 conv, QK^T and PV on MFMA,
@@ -22,6 +27,7 @@ Layer order restates models.py:301-341 (forward), :115-134 (ResnetBlock),
 :165-189 (AttnBlock), :61-71 (Downsample), :47-51 (Upsample).
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -29,6 +35,8 @@ import torch
 from .. import ops
 
 GN_EPS = 1e-6          # models.py:33
+# DDNM_CONV_F32=mfma32: every convolution on the fp32 MFMA instruction (the pre-split engine; A/B switch)
+SPLIT16 = os.environ.get("DDNM_CONV_F32", "split16") != "mfma32"
 CIN_PAD = 32           # conv_in reads the image through a 32-channel NHWC staging tensor
 
 
@@ -208,6 +216,16 @@ class Model:
             w[f"{n}.conv1.weight"] = ops.pack_conv_weight(g(f"{n}.conv1.weight"))
             w[f"{n}.conv2.weight"] = ops.pack_conv_weight(g(f"{n}.conv2.weight"))
             w[f"{n}.conv2.bias"] = g(f"{n}.conv2.bias")
+            if SPLIT16:
+                # split-fp16 packing (fp32-grade products on the fp16 matrix pipe, ops.pack_conv_weight_s16); conv2 and
+                # its fused shortcut share an accumulator, hence one scale
+                w1, w2 = g(f"{n}.conv1.weight"), g(f"{n}.conv2.weight")
+                wsk = g(f"{n}.nin_shortcut.weight") if rb.cin != rb.cout else None
+                s1 = ops.s16_weight_scale(w1)
+                s2 = ops.s16_weight_scale(w2) if wsk is None else ops.s16_weight_scale(w2, wsk)
+                w[f"{n}.conv1.s16"] = (ops.pack_conv_weight_s16(w1, s1), s1, None)
+                w[f"{n}.conv2.s16"] = (ops.pack_conv_weight_s16(w2, s2), s2,
+                                       None if wsk is None else ops.pack_conv_weight_s16(wsk, s2))
             # conv1 bias folded into the (concatenated) temb projection: h = conv1(.) + b1 + proj(temb)
             tw.append(g(f"{n}.temb_proj.weight"))
             tb.append(g(f"{n}.temb_proj.bias") + g(f"{n}.conv1.bias"))
@@ -236,6 +254,10 @@ class Model:
         for lvl, (_, _, has_up, c) in self.up.items():
             if has_up:
                 w[f"up.{lvl}.upsample.conv.weight"] = ops.pack_conv_weight(g(f"up.{lvl}.upsample.conv.weight"))
+                if SPLIT16:
+                    wu = g(f"up.{lvl}.upsample.conv.weight")
+                    su = ops.s16_weight_scale(wu)
+                    w[f"up.{lvl}.upsample.conv.s16"] = (ops.pack_conv_weight_s16(wu, su), su, None)
                 w[f"up.{lvl}.upsample.conv.bias"] = g(f"up.{lvl}.upsample.conv.bias")
         w["norm_out.weight"], w["norm_out.bias"] = g("norm_out.weight"), g("norm_out.bias")
         w["conv_out.weight"] = ops.pack_conv_weight(g("conv_out.weight"))
@@ -276,20 +298,25 @@ class Model:
         w, n = self.w, rb.name
         gn1 = self._gn(x0, x1, n + ".norm1")
         h = ops.conv2d(x0, w[n + ".conv1.weight"], rb.cout, 3, src1=x1, gn=gn1, gn_silu=True,
-                       badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total, emit_stats=True)
+                       badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total, emit_stats=True,
+                       weight_s16=w.get(n + ".conv1.s16"))
         gn2 = self._gn(h, None, n + ".norm2")
         if rb.cin != rb.cout:
             B, H, W, _ = h.t.shape
             if ops.conv_fuses_skip(B, H, W, rb.cout, rb.cout):
                 return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True,
                                   bias=w[n + ".conv2_plus_shortcut.bias"], skip=(x0, x1),
-                                  skip_weight=w[n + ".nin_shortcut.fused"], emit_stats=True)
+                                  skip_weight=w[n + ".nin_shortcut.fused"], emit_stats=True,
+                                  weight_s16=w.get(n + ".conv2.s16"))
             xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"])
         else:
             assert x1 is None
             xs = x0
+        s16 = w.get(n + ".conv2.s16")
+        if s16 is not None:
+            s16 = (s16[0], s16[1], None)         # un-fused shortcut: the 3x3 weights alone (same packing, same scale)
         return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True, bias=w[n + ".conv2.bias"],
-                          res=xs, emit_stats=True)
+                          res=xs, emit_stats=True, weight_s16=s16)
 
     def _attn(self, a, x):
         w, n = self.w, a.name
@@ -367,7 +394,8 @@ class Model:
                     h = self._attn(attns[ib], h)
             if has_up:
                 n = f"up.{lvl}.upsample.conv"
-                h = ops.conv2d(h, w[n + ".weight"], c, 3, bias=w[n + ".bias"], ups=True, emit_stats=True)
+                h = ops.conv2d(h, w[n + ".weight"], c, 3, bias=w[n + ".bias"], ups=True, emit_stats=True,
+                               weight_s16=w.get(n + ".s16"))
         gn = self._gn(h, None, "norm_out")
         return ops.conv2d(h, w["conv_out.weight"], self.out_ch, 3, gn=gn, gn_silu=True, bias=w["conv_out.bias"],
                           out_nchw=True)

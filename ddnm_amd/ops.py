@@ -118,6 +118,49 @@ def pack_conv_weight_f16(w, cin_pad=None):
     return pack_conv_weight(w, cin_pad=cin_pad).to(torch.float16).contiguous()
 
 
+def s16_weight_scale(*ws):
+    """The power of two 2^s that brings max|W| of a launch's weight tensors (3x3 kernel + fused shortcut: they share
+    one accumulator) into [2^13, 2^14): fp16 `hi` parts stay far from 65504 and the `lo` parts of all but negligible
+    weights are normal fp16 numbers (include/ddnm_hip.h::ddnm_conv3x3_s16_f32)."""
+    import math
+    m = max(float(w.abs().max()) for w in ws)
+    if not (m > 0.0) or not math.isfinite(m):
+        return 1.0
+    return 2.0 ** (13 - math.floor(math.log2(m)))
+
+
+def pack_conv_weight_s16(w, scale):
+    """OIHW fp32 -> the split packing of ddnm_conv3x3_s16_f32: (O, ky, kx, I) with Cout padded to 128, every 32-channel
+    chunk stored as 32 hi halfs then 32 lo halfs of scale * W (hi = rn16, lo = rn16(residual)); returned as an fp16
+    tensor [Cout_pad][taps][Cin/32][2][32] (= the byte size of the fp32 packing)."""
+    p = pack_conv_weight(w) * float(scale)                      # [Cout_pad][taps][Cin], power-of-two scaling: exact
+    cp, taps, cin = p.shape
+    if cin % 32:
+        raise ValueError("split packing needs Cin % 32 == 0")
+    hi = p.to(torch.float16)
+    lo = (p - hi.float()).to(torch.float16)
+    hi, lo = hi.view(cp, taps, cin // 32, 1, 32), lo.view(cp, taps, cin // 32, 1, 32)
+    return torch.cat([hi, lo], 3).contiguous()
+
+
+def conv_runs_s16(B, H, W, cin, cout, ups=False):
+    """True when a 3x3 / stride-1 conv of this OUTPUT shape takes the split-fp16 kernel (given split-packed weights)."""
+    d = ConvDesc()
+    d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, H, W, cin, 0, cout
+    d.ksize, d.stride, d.pad, d.Ho, d.Wo = 3, 1, 1, H, W
+    return _lib.lib().ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1
+
+
+_S16_ACT_SCALE = None
+
+
+def _s16_act_scale():
+    global _S16_ACT_SCALE
+    if _S16_ACT_SCALE is None:
+        _S16_ACT_SCALE = float(_lib.lib().ddnm_conv3x3_s16_act_scale())
+    return _S16_ACT_SCALE
+
+
 def conv_runs_f16(B, H, W, cin, cout, ksize=3):
     """True when a stride-1 conv of this shape takes the fp16-operand kernel (given packed fp16 weights)."""
     d = ConvDesc()
@@ -144,9 +187,11 @@ def _f16_scratch(device, numel, slot=0):
 
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
-           emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None):
+           emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None, weight_s16=None):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
-    With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them)."""
+    With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them).
+    weight_s16 = (packed, scale, packed_skip or None) from pack_conv_weight_s16: 3x3 / stride-1 launches whose shape
+    qualifies then run the split-fp16 kernel (fp32-grade products on the fp16 matrix pipe) instead of the fp32 one."""
     src0 = src0.t if isinstance(src0, Act) else src0
     src1 = src1.t if isinstance(src1, Act) else src1
     res = res.t if isinstance(res, Act) else res
@@ -187,6 +232,11 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
     # shape qualifies; everything else runs the exact-fp32 kernels
     f16, f16_1x1 = False, False
+    s16 = (weight_s16 is not None and weight_f16 is None and ksize == 3 and stride == 1
+           and (skip is None or weight_s16[2] is not None) and L.ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1)
+    if s16:
+        d.weight = weight_s16[0].data_ptr()
+        d.acc_scale = 1.0 / (float(weight_s16[1]) * _s16_act_scale())
     if weight_f16 is not None:
         if ksize == 3:
             f16 = L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
@@ -227,13 +277,15 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         s1 = None if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1])
         d.skip0, d.skip1 = _p(s0), _p(s1)
         d.SC0, d.SC1 = s0.shape[3], (0 if s1 is None else s1.shape[3])
-        d.skip_weight = _p(skip_weight_f16) if f16 else _p(skip_weight)
+        d.skip_weight = _p(skip_weight_f16) if f16 else (weight_s16[2].data_ptr() if s16 else _p(skip_weight))
         if f16 and skip_weight_f16 is None:
             raise ValueError("fp16 launch with a fused shortcut needs skip_weight_f16")
     if f16_1x1:
         fn_run, fn_tiles, fn_ws = L.ddnm_conv1x1_f16_f32, L.ddnm_conv1x1_f16_stats_tiles, L.ddnm_conv1x1_f16_workspace_floats
     elif f16:
         fn_run, fn_tiles, fn_ws = L.ddnm_conv3x3_f16_f32, L.ddnm_conv3x3_f16_stats_tiles, L.ddnm_conv3x3_f16_workspace_floats
+    elif s16:
+        fn_run, fn_tiles, fn_ws = L.ddnm_conv3x3_s16_f32, L.ddnm_conv3x3_s16_stats_tiles, L.ddnm_conv3x3_s16_workspace_floats
     else:
         fn_run, fn_tiles, fn_ws = L.ddnm_conv2d_f32, L.ddnm_conv2d_f32_stats_tiles, L.ddnm_conv2d_f32_workspace_floats
     stats, tiles = None, 0
@@ -253,6 +305,8 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
             variant = "conv1x1_f16<256x128>"
         elif f16:
             variant = "conv3x3_halo_f16<256x128>"
+        elif s16:
+            variant = "conv3x3_halo_s16<256x128>"
         else:
             tn = L.ddnm_conv2d_f32_tile_n(ctypes.byref(d))
             kind = "conv3x3_halo_f32" if (ksize == 3 and stride == 1) else "conv_gather_f32"

@@ -28,7 +28,7 @@ extern "C" {
 #define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
 #define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
 
-int ddnm_version(void);                 /* ABI version, currently 3 (bumped on every struct / prototype change) */
+int ddnm_version(void);                 /* ABI version, currently 4 (bumped on every struct / prototype change) */
 const char* ddnm_build_digest(void);    /* sha256 of the sources + flags this binary was built from (build.py) */
 int ddnm_sizeof(int which);             /* sizeof of 0: ddnm_conv_desc, 1: ddnm_gemm_desc, 2: ddnm_conv16_desc,
                                            3: ddnm_step_scalars as compiled into the binary (-1: unknown index) */
@@ -86,6 +86,9 @@ typedef struct ddnm_conv_desc {
     const float* skip1;     /* NHWC [B][Ho][Wo][SC1] or NULL */
     const float* skip_weight; /* packed [Cout_pad][SC0+SC1] (fp16 for ddnm_conv3x3_f16_f32) */
     int32_t SC0, SC1;
+    float acc_scale;        /* ddnm_conv3x3_s16_f32 only: power of two that multiplies the accumulator before bias / residual
+                               (undoes the operand pre-scaling of the split form); ignored by the other entry points */
+    int32_t reserved0;
 } ddnm_conv_desc;
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
@@ -115,6 +118,24 @@ int ddnm_conv3x3_f16_f32(const ddnm_conv_desc* d, void* stream);
 int ddnm_conv3x3_f16_supported(const ddnm_conv_desc* d);
 int64_t ddnm_conv3x3_f16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d);
+
+/* 3x3 / stride 1 / pad 1 convolution of fp32 tensors with fp32-GRADE products on the fp16 matrix pipe (the celeba
+ * `Model`, guided_diffusion/models.py:87,96,225 -- the reference runs it in fp32): every operand value v is carried as
+ * hi = rn16(v), lo = rn16(v - hi), a product is hi*hi' + hi*lo' + lo*hi' (three v_mfma_f32_32x32x16_f16 whose fp16 x fp16
+ * products are exact in the fp32 accumulator; the dropped lo*lo' term is 2^-22 relative), so the operand error is
+ * <= 2^-22 -- below the accumulation noise of an fp32 dot product of this length -- at 16/3 of the fp32 MFMA rate.
+ * Same descriptor as ddnm_conv2d_f32 (GroupNorm + swish prologue, concat, x2 upsample, fused shortcut, bias / badd /
+ * residual, statistics, split-K) except:
+ *   weight / skip_weight = the SPLIT packing: per (output row, tap, 32-channel chunk) 32 hi halfs then 32 lo halfs of
+ *     2^s * W (the byte size of the fp32 (O,ky,kx,I) array), Cout padded to 128; one power of two 2^s per launch that
+ *     brings max|W| into [2^13, 2^14) so that lo is a normal fp16 number;
+ *   acc_scale = 2^-s (times the inverse of the kernel's compile-time activation pre-scale, ddnm_conv3x3_s16_act_scale()).
+ * Needs Cin % 32 == 0, C0 % 32 == 0, Cout % 128 == 0, Ho*Wo % 256 == 0 (else: ddnm_conv2d_f32). */
+int ddnm_conv3x3_s16_f32(const ddnm_conv_desc* d, void* stream);
+int ddnm_conv3x3_s16_supported(const ddnm_conv_desc* d);
+int64_t ddnm_conv3x3_s16_workspace_floats(const ddnm_conv_desc* d);
+int ddnm_conv3x3_s16_stats_tiles(const ddnm_conv_desc* d);
+float ddnm_conv3x3_s16_act_scale(void);   /* power of two the kernel multiplies activations with before splitting them */
 
 /* 1x1 convolution with fp16 MFMA operands, fp32 accumulate / output: the attention blocks' qkv and proj_out
  * Conv1d(k=1) and un-fused 1x1 shortcuts of the `use_fp16` torso (guided_diffusion/unet.py:222,283-289,301-308).
