@@ -34,6 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 MFMA (= vector) peak
+# The 3x3 layers of the headline workload run fp32-GRADE products on the fp16 matrix pipe: one product = three
+# v_mfma_f32_32x32x16_f16 products (hi*hi + hi*lo + lo*hi, ddnm_conv3x3_s16_f32).  `achieved` counts ALGORITHMIC FLOPs
+# (one multiply-add per product), so the bound of that kernel is a third of the dense fp16 MFMA peak.
+PEAK_SPLIT16_TFLOPS = round(2500.0 / 3.0, 1)
 FLOPS_PER_FWD_PER_IMAGE = 498.35e9   # SURVEY.md section 8(d), celeba Model
 T_SAMPLING = 100
 BATCH_PER_GPU = 8
@@ -414,9 +418,10 @@ def main():
     y = op.A(x_orig)
     torch.cuda.manual_seed(1234 + rank)
 
-    def one_pass():
+    def one_pass(m=None):
         x_T = torch.randn(B, 3, 256, 256, device=dev)
-        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg, return_cpu=False)
+        xs, _ = ddnm_diffusion(x_T, model if m is None else m, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg,
+                               return_cpu=False)
         return ddist.gather_images(xs[0])            # the path's single collective
 
     for _ in range(args.warmup):
@@ -441,7 +446,11 @@ def main():
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "ms_per_step_rank_min": round(dt_min / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "backend": dist_info["backend"], "ranks_seen": ranks_seen,
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f32 (3x3 convolutions: fp32 operands carried as hi + lo fp16 halves, three fp16 MFMA products per "
+                  "product, fp32 accumulate -- operand error 2^-22, measured closer to fp64 than the fp32 MFMA kernel; "
+                  "everything else fp32)") if getattr(model, "split16", False) else "f32",
+        "data": "synthetic",
         "config": {"workload": "celeba_hq.yml SVD sr_bicubic 4x, sigma_y=0, eta=0.85, T_sampling=100, "
                                "batch_size=8 per GPU (BASELINE configs[1])",
                    "global_batch": B * world, "image": "3x256x256", "parallelism": f"dp{world} (image sharding)"},
@@ -472,6 +481,12 @@ def main():
                                       + b_ * ho * wo * cout * (2 if has_res else 1)))
             total_ms = sum(v["ms"] for v in summ.values())
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            if name.startswith("conv3x3_halo_s16"):
+                peak = PEAK_SPLIT16_TFLOPS
+                peak_note = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: one fp32-grade product = three fp16 MFMA products; "
+                             "`achieved` counts algorithmic FLOPs (x3 = %.0f TFLOP/s of MFMA work)" % (3 * achieved))
+            else:
+                peak, peak_note = PEAK_F32_TFLOPS, "fp32 MFMA peak"
             traffic, mfma_busy, frac_rocprof, pmc_note = None, None, None, \
                 "no profiles/*_pmc_dominant_kernel.json carries the loaded library's source digest: traffic / MFMA-busy " \
                 "are not reported for this binary"
@@ -481,12 +496,13 @@ def main():
                 traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_busy_frac_weighted")
                 if pj.get("rocprof_avg_launch_us"):
                     frac_rocprof = round(r["flops"] / r["launches"] / (pj["rocprof_avg_launch_us"] * 1e-6) / 1e12
-                                         / PEAK_F32_TFLOPS, 4)
+                                         / peak, 4)
                 pmc_note = f"HBM bytes per launch = FETCH_SIZE x2 + WRITE_SIZE, MFMA-busy and the rocprofv3 average " \
                            f"launch time from profiles/{fname} (same source digest as the loaded library)"
             line["roofline"] = {
-                "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": traffic,
+                "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                "peak_note": peak_note,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "frac_rocprof": frac_rocprof, "traffic_note": pmc_note,
                 "traffic_algorithmic": round(sum(alg) / max(1, len(alg)), 1),
                 "mfma_busy_pmc": mfma_busy,
@@ -494,11 +510,37 @@ def main():
                 "avg_flops_per_launch": r["flops"] / r["launches"],
                 "share_of_conv_time": round(r["ms"] / total_ms, 4),
                 "whole_loop_tflops": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world, 2),
-                "whole_loop_frac": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world / PEAK_F32_TFLOPS, 4),
+                "whole_loop_frac": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world / peak, 4),
             }
         except Exception as e:    # noqa: BLE001
             ops.set_kernel_timer(None)
             line["roofline"] = {"error": repr(e)}
+    if world == 1 and getattr(model, "split16", False) and not args.no_roofline:
+        # the same restoration (same noise) on the all-fp32-MFMA engine: its speed, and how far the two results are apart
+        try:
+            model32 = Model(cfg, device=dev, split16=False)
+            model32.load_state_dict(sd)
+            one_pass(model32)                                   # warm-up
+            torch.cuda.manual_seed(4321)
+            out_s = one_pass()
+            torch.cuda.manual_seed(4321)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            out_f = one_pass(model32)
+            torch.cuda.synchronize()
+            dt32 = time.perf_counter() - t1
+
+            line["f32_mfma_path"] = {
+                "value": round(B / dt32, 4), "unit": "images/sec",
+                "note": "same workload with every convolution on v_mfma_f32_32x32x2_f32 (DDNM_CONV_F32=mfma32), 1 pass; "
+                        "the differences are between the two engines' restorations of the same inputs and noise",
+                "restoration_rel_l2_diff": float((out_s - out_f).double().norm() / out_f.double().norm()),
+                "restoration_max_abs_diff": float((out_s - out_f).abs().max()),
+                "restoration_max_abs": float(out_f.abs().max()),
+            }
+            del model32, out_s, out_f
+        except Exception as e:    # noqa: BLE001
+            line["f32_mfma_path"] = {"error": repr(e)}
     if world > 1:
         ddist.barrier()
     if not args.no_extra_workloads:

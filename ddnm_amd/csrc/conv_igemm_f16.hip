@@ -11,13 +11,18 @@
 // Structure = the fp32 halo kernel scaled for a 16x faster matrix pipe:
 //   workgroup 512 threads = 8 waves (4 x 2), wave tile 64 x 64 (2 x 2 MFMA tiles), block tile
 //   256 pixels (8 x 32 patch, halo 10 x 34) x 128 output channels, K chunk = 64 channels;
-//   LDS: halo [340][64+8] fp16 (49 KB) + weight tile [128][64+8] fp16 double-buffered (37 KB);
-//   row pitch 144 B = 36 dwords keeps ds_read_b128 conflict-free (one read = 8 k-values of a row);
-//   per tap and wave: 16 MFMAs (512 cycles) between barriers, weight tile of tap+2 in flight.
+//   LDS: halo [340][64+8] fp16 double-buffered (2 x 49 KB; row pitch 144 B = 36 dwords keeps ds_read_b128
+//   conflict-free, one read = 8 k-values of a row) + THREE weight tiles [128][64] fp16 (3 x 16 KB) that arrive by
+//   LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass): unpadded lane-linear image, bank
+//   conflicts removed by an XOR swizzle of the 16-byte piece index with (row >> 1) & 7 applied to the per-lane SOURCE
+//   address and to the fragment read address; the tile of tap+2 is requested while tap is multiplied (an L2 round
+//   trip is longer than one tap of MFMAs: with register staging one tap ahead the loads cost 20 % of the kernel);
+//   per tap and wave: 16 (split form: 24) MFMAs between barriers.
 #include "conv_common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Build-time tile variants for probing (tools/conv16_ablate.py): -DDDNM_F16_KC=32 -DDDNM_F16_BM=512 is the 8-wave
 // 512x128 block with 128x64 wave tiles (25 % fewer LDS fragment reads per MFMA); defaults = the production tile.
@@ -27,12 +32,23 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #ifndef DDNM_F16_BM
 #define DDNM_F16_BM 256
 #endif
+#ifndef DDNM_F16_KS_TARGET
+#define DDNM_F16_KS_TARGET 256      // split-K: workgroups a low-resolution launch is spread over.  ONE workgroup fits a CU
+                                    // (151 KB of LDS), so 256 = a single round; 512 (the fp32 kernel's figure, two
+                                    // workgroups per CU) doubles the fp32 slab traffic for nothing: 32^2 / 16^2 layers
+                                    // of the celeba UNet at B = 8 run 12-29 % faster with 256 (tools/s16_probe.py)
+#endif
 constexpr int KC16 = DDNM_F16_KC;   // channels per chunk
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 
 // fp32 x4 -> hi | lo fp16 halves of a split row: hi at dst, lo 32 halfs behind it (conv3x3_halo_f16_kernel<.., SPLIT>)
 #ifndef DDNM_S16_ASCALE
-#define DDNM_S16_ASCALE 1.0f        // power-of-two pre-scale of the activation operand (undone by acc_scale)
+// Power-of-two pre-scale of the activation operand (undone by acc_scale).  `lo` = rn16(v - hi) is a NORMAL fp16 number
+// for |16 v| >= 0.25; below that it loses bits one by one (the MFMA honours fp16 subnormals; the absolute error of
+// hi + lo stays <= 2^-25 / 16), so operands of magnitude >= 2^-6 -- every GroupNorm'd / residual-stream tensor of the
+// network -- keep the 2^-22 relative bound, and a tensor that is uniformly ~1e-4 still keeps ~1e-5.  fp16 overflow starts
+// at |v| = 4094, far above any activation of the network (a larger scale would trade that margin away).
+#define DDNM_S16_ASCALE 16.0f
 #endif
 __device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {
     v = v * DDNM_S16_ASCALE;
@@ -66,13 +82,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     constexpr int HCOLS = KCH / HVEC;                             // loads per halo row of one chunk
     constexpr int HROWS_PER_PASS = NTHREADS / HCOLS;
     constexpr int HR = (MAXH + HROWS_PER_PASS - 1) / HROWS_PER_PASS;
-    constexpr int BCOLS = KC16 / 8;                               // 16-byte pieces per weight row of one chunk
+    static_assert(KC16 == 64, "an LDS weight row is 128 bytes");
+    constexpr int BCOLS = 8;                                      // 16-byte pieces per weight row of one chunk
     constexpr int BROWS_PER_PASS = NTHREADS / BCOLS;
-    constexpr int BR = BN / BROWS_PER_PASS;
+    constexpr int BR = BN / BROWS_PER_PASS;                       // LDS-DMA instructions per wave and weight tile
     static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
-    __shared__ __attribute__((aligned(16))) _Float16 Hs[2 * MAXH * LDH];      // halo double-buffered (see main loop)
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * BN * LDH];
-    __shared__ __attribute__((aligned(16))) float stat_lds[WM * BN * 2];
+    constexpr int NWB = 3;                                        // weight tiles in LDS (tap, tap+1, tap+2)
+    constexpr int WTILE = BN * 128;                               // bytes of one weight tile
+    constexpr int HBYTES = 2 * MAXH * LDH * 2;                    // halo, double-buffered (see main loop)
+    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read)
+    __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + HBYTES + WM * BN * 2 * 4];
+    char* const Bs = lds_all;
+    _Float16* const Hs = reinterpret_cast<_Float16*>(lds_all + NWB * WTILE);
+    float* const stat_lds = reinterpret_cast<float*>(lds_all + NWB * WTILE + HBYTES);
 
     const ddnm_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,9 +119,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
         hoff[i] = ok ? (img * p.Hs + sy) * p.Ws + sx : -1;
     }
-    // ---- weight loader mapping: thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
+    // ---- weight tile of (chunk, tap) -> Bs[buf] by LDS-DMA: one instruction moves 8 rows x 128 B; lane ->
+    // (row = 8*g + lane/8, piece lane%8) and the piece it FETCHES is piece ^ swizzle(row), so the linear image holds the
+    // swizzled layout.  Rows of wave w: 8w + lrow + 64 j, so (row >> 1) & 7 = 4 (w & 1) + (lrow >> 1) for every j.
+    const int lrow = lane >> 3, lpiece = lane & 7;
+    const int wswz = (((wave & 1) << 2) | (lrow >> 1));
+    const unsigned w_rowlen = 9u * (unsigned)p.Cin * WE * 2u;                 // bytes per output-channel row
+    const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(d.weight)), 0, (unsigned)p.n_tiles * BN * w_rowlen, 0x00020000);
+    const unsigned w_voff = (unsigned)(n_tile * BN + wave * 8 + lrow) * w_rowlen + (unsigned)((lpiece ^ wswz) * 16);
+    auto issue_w = [&](int chunk, int tap, int buf) {
+#ifndef DDNM_PROBE16_NO_BLOAD
+        char* dst = Bs + buf * WTILE + wave * 1024;
+        const unsigned so = ((unsigned)tap * p.Cin + (unsigned)chunk * KCH) * WE * 2u;
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(dst + j * (NTHREADS / 64) * 1024),
+                                                     16, w_voff, so + (unsigned)j * (NTHREADS / 8) * w_rowlen, 0, 0);
+#endif
+    };
+    // register-staged weights (fused shortcut only): thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
     const int c8 = tid % BCOLS, brow = tid / BCOLS;
-    const _Float16* wbase = reinterpret_cast<const _Float16*>(d.weight) + (size_t)(n_tile * BN + brow) * 9 * p.Cin * WE + c8 * 8;
 
     const int nchunks = p.Cin / KCH;
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
@@ -114,19 +154,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const bool has_gn = !SRC16 && d.gn_scale != nullptr;
 
     constexpr int HSPLIT = (HR + 1) / 2;            // row slots [0, HSPLIT) and [HSPLIT, HR) are loaded / staged separately
+    // Halo loads are buffer loads with an out-of-range offset for padding / unused rows (the load returns zero): every
+    // wave then issues EXACTLY i1 - i0 (+ 2 GroupNorm vectors with part 0) requests per call, which is what lets the
+    // main loop leave them in flight across a barrier with a counted `s_waitcnt vmcnt(N)`.
+    constexpr int ESZ = SRC16 ? 2 : 4;
+    constexpr unsigned HOOB = 0x80000000u;          // every tensor here is < 2 GB (checked by the host)
+    const __amdgpu_buffer_rsrc_t r_s0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(d.src0)), 0, (unsigned)d.B * p.Hs * p.Ws * d.C0 * ESZ, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_s1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(d.C1 > 0 ? d.src1 : d.src0)), 0,
+        (unsigned)d.B * p.Hs * p.Ws * (d.C1 > 0 ? d.C1 : d.C0) * ESZ, 0x00020000);
     auto prefetch_halo_part = [&](int chunk, int i0, int i1) {
         const int cb = chunk * KCH;
-        const char* src;
-        int cs, coff;
-        if (cb < d.C0) { src = reinterpret_cast<const char*>(d.src0); cs = d.C0; coff = cb; }
-        else { src = reinterpret_cast<const char*>(d.src1); cs = d.C1; coff = cb - d.C0; }
-        constexpr int ESZ = SRC16 ? 2 : 4;
+        const bool first = cb < d.C0;
+        const unsigned cs = first ? d.C0 : d.C1, coff = first ? cb : cb - d.C0;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             if (i < i0 || i >= i1) continue;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (hoff[i] >= 0) v = *reinterpret_cast<const uint4*>(src + ((size_t)hoff[i] * cs + coff + hc * HVEC) * ESZ);
-            h_st[i] = v;
+            const unsigned vo = hoff[i] >= 0 ? ((unsigned)hoff[i] * cs + hc * HVEC) * ESZ : HOOB;
+            const u32x4 v = first ? __builtin_amdgcn_raw_buffer_load_b128(r_s0, vo, coff * ESZ, 0)
+                                  : __builtin_amdgcn_raw_buffer_load_b128(r_s1, vo, coff * ESZ, 0);
+            h_st[i] = uint4{v.x, v.y, v.z, v.w};
         }
         if constexpr (!SRC16) {
             if (has_gn && i0 == 0) {
@@ -136,21 +184,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         }
     };
     auto prefetch_halo = [&](int chunk) { prefetch_halo_part(chunk, 0, HR); };
-    auto prefetch_b = [&](int chunk, int tap) {
-        const _Float16* wp = wbase + ((size_t)tap * p.Cin + chunk * KCH) * WE;
-#ifdef DDNM_PROBE16_NO_BLOAD
-        if (chunk < 0) {
-#endif
-        b_st0 = *reinterpret_cast<const uint4*>(wp);
-        if constexpr (BR >= 2) b_st1 = *reinterpret_cast<const uint4*>(wp + (size_t)BROWS_PER_PASS * 9 * p.Cin * WE);
-        if constexpr (BR == 4) {
-            b_st2 = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * BROWS_PER_PASS) * 9 * p.Cin * WE);
-            b_st3 = *reinterpret_cast<const uint4*>(wp + (size_t)(3 * BROWS_PER_PASS) * 9 * p.Cin * WE);
-        }
-#ifdef DDNM_PROBE16_NO_BLOAD
-        }
-#endif
-    };
     auto stage_halo_part = [&](int hbuf, int i0, int i1) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
@@ -162,7 +195,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                     *reinterpret_cast<uint4*>(dst) = h_st[i];
                 } else {
                     f32x4 v = __builtin_bit_cast(f32x4, h_st[i]);
+#ifndef DDNM_PROBE_NO_GN              // timing probe (wrong results): no GroupNorm affine / swish in the loader
                     if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
+#endif
                     if constexpr (SPLIT) {
                         split_store(dst, v);
                     } else {
@@ -173,13 +208,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             }
         }
     };
-    auto stage_b = [&](int buf) {
-        _Float16* dst = &Bs[buf * BN * LDH + brow * LDH + c8 * 8];
-        *reinterpret_cast<uint4*>(dst) = b_st0;
-        if constexpr (BR >= 2) *reinterpret_cast<uint4*>(dst + BROWS_PER_PASS * LDH) = b_st1;
+    auto stage_b = [&](int buf) {          // register-staged weights (fused shortcut): the same swizzled image
+        char* dst = Bs + buf * WTILE;
+        auto put = [&](int r, const uint4& v) { *reinterpret_cast<uint4*>(dst + r * 128 + ((c8 ^ ((r >> 1) & 7)) << 4)) = v; };
+        put(brow, b_st0);
+        if constexpr (BR >= 2) put(brow + BROWS_PER_PASS, b_st1);
         if constexpr (BR == 4) {
-            *reinterpret_cast<uint4*>(dst + 2 * BROWS_PER_PASS * LDH) = b_st2;
-            *reinterpret_cast<uint4*>(dst + 3 * BROWS_PER_PASS * LDH) = b_st3;
+            put(brow + 2 * BROWS_PER_PASS, b_st2);
+            put(brow + 3 * BROWS_PER_PASS, b_st3);
         }
     };
 
@@ -198,12 +234,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         const int ty = m >> p.TW_log2, tx = m & (p.TW - 1);
         a_off[i] = (ty * HWd + tx) * LDH + (lane >> 5) * 8;
     }
-    const _Float16* b_frag = Bs + (wn * NT * 32) * LDH + (lane & 31) * LDH + (lane >> 5) * 8;
+    // B fragment of 16-byte piece q (+ lane >> 5): row n = wn*NT*32 + j*32 + (lane & 31), swizzled with (n >> 1) & 7 =
+    // ((lane & 31) >> 1) & 7; the piece pair 2 q enters as an XOR of bits 5-6 of the byte address
+    const int b_frag = ((wn * NT * 32 + (lane & 31)) * 128) + ((((lane >> 5) ^ (((lane & 31) >> 1) & 7))) << 4);
 
     auto mfma_tap = [&](int tap, int buf, int hbuf = 0) {
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int tap_off = (ky * HWd + kx) * LDH + hbuf * MAXH * LDH;
-        const _Float16* bf = b_frag + buf * BN * LDH;
+        const char* bf = Bs + buf * WTILE;
         if constexpr (SPLIT) {
             // [hi 32 | lo 32] rows: k-step ks reads the hi fragment at ks*16 and the lo fragment 32 halfs behind it;
             // the three products of one (i, j) tile are spread over the loop so that no MFMA waits on its predecessor
@@ -217,8 +255,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16);
-                    bl[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16 + 32);
+                    bh[j] = *reinterpret_cast<const half8*>(bf + ((b_frag ^ (ks << 5)) + j * 32 * 128));
+                    bl[j] = *reinterpret_cast<const half8*>(bf + ((b_frag ^ ((ks + 2) << 5)) + j * 32 * 128));
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -244,7 +282,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #pragma unroll
             for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const half8*>(bf + j * 32 * LDH + ks * 16);
+            for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const half8*>(bf + ((b_frag ^ (ks << 5)) + j * 32 * 128));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -253,38 +291,60 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
         }
     };
 
-    // Main loop.  Weight tile: double-buffered, loads two taps ahead (one barrier per tap).  Halo: double-buffered
-    // too -- the next chunk's halo is loaded in two halves (taps 0 and 3) and converted / GroupNorm'd / written
-    // to the OTHER halo buffer at taps 3 and 6, between MFMA batches, so a chunk boundary costs nothing
-    // (re-staging it between two barriers used to be 28 % of the kernel).
+    // Main loop, one barrier per tap:  [my pieces of W(s) landed | barrier: everybody's; the buffer of W(s-1) is free |
+    // request W(s+2) into it | MFMA(s)].  Halo: double-buffered -- the next chunk's halo is loaded in two halves
+    // (taps 0 and 3) and converted / GroupNorm'd / written to the OTHER halo buffer at taps 3 and 6, between MFMA
+    // batches, so a chunk boundary costs nothing (re-staging it between two barriers used to be 28 % of the kernel).
 #ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
     if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
 #endif
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
-        prefetch_b(c_begin, 0);
+        const int last_step = (c_end - c_begin) * 9 - 1;
+        // request of step q (clamped to the last one: the tail re-requests a tile nobody reads, which keeps the
+        // `vmcnt` bookkeeping of the loop uniform)
+        auto issue_step = [&](int q, int buf) {
+            q = q < last_step ? q : last_step;
+            const int ch = q / 9;
+            issue_w(c_begin + ch, q - 9 * ch, buf);
+        };
+        issue_step(0, 0);
+        issue_step(1, 1);
         stage_halo_part(0, 0, HR);
-        stage_b(0);
-        prefetch_b(c_begin, 1);
-        __syncthreads();
-        int cur = 0, hb = 0;
-        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        int hb = 0, step0 = 0;
+        for (int chunk = c_begin; chunk < c_end; ++chunk, step0 += 9) {
             const bool more = chunk + 1 < c_end;
+            // unrolled: in a rolled loop the compiler guards the halo loads into registers (taps 0 / 3) with a full
+            // `vmcnt(0)` in front of every tap's fragment reads, which would drain the two tiles in flight
+#pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const bool last_tap = tap == 8;
-                if (!last_tap || more) {
-                    stage_b(cur ^ 1);
-                    if (tap < 7) prefetch_b(chunk, tap + 2);
-                    else if (tap == 7) { if (more) prefetch_b(chunk + 1, 0); }
-                    else if (more) prefetch_b(chunk + 1, 1);
+                const int cur = tap % NWB, step = step0 + tap;      // 9 % 3 == 0: W(step) sits in buffer tap % 3
+                // in order behind W(step): W(step+1) = BR requests (+ halo loads into registers, waited for where used)
+                // (raw s_barrier: __syncthreads() would drain the whole queue -- `vmcnt(0)` -- in front of it; lgkmcnt(0) =
+                // this wave's halo ds_writes of taps 3 / 6 are in LDS before anybody can be past the barrier)
+                // the halo loads of taps 0 / 3 (requested behind W(step+2) of those taps, i.e. younger than the tile awaited
+                // here at the two following taps) stay in flight as well: they come from HBM and are not needed before
+                // taps 3 / 6, where the compiler waits for their registers
+                if ((tap == 1 || tap == 2) && more) {
+                    if (has_gn) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HSPLIT + 2) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HSPLIT) : "memory");
+                } else if ((tap == 4 || tap == 5) && more) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HR - HSPLIT) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
                 }
+#ifndef DDNM_PROBE16_NO_TAP_BARRIER
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#endif
+                issue_step(step + 2, cur >= 1 ? cur - 1 : NWB - 1);     // (step + 2) % 3: the buffer W(step - 1) just left
                 if (more) {
                     if (tap == 0) prefetch_halo_part(chunk + 1, 0, HSPLIT);
                     if (tap == 3) { stage_halo_part(hb ^ 1, 0, HSPLIT); prefetch_halo_part(chunk + 1, HSPLIT, HR); }
                     if (tap == 6) stage_halo_part(hb ^ 1, HSPLIT, HR);
                 }
 #ifndef DDNM_PROBE16_NO_SCHED_BARRIER
-                // keep the global loads issued above in front of this tap's MFMAs: left alone, the scheduler sinks
+                // keep the requests issued above in front of this tap's MFMAs: left alone, the scheduler sinks
                 // them behind the MFMAs (VGPR pressure) and their latency lands on the barrier of every tap
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -295,14 +355,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #ifdef DDNM_PROBE_SETPRIO_MFMA
                 __builtin_amdgcn_s_setprio(0);
 #endif
-#ifndef DDNM_PROBE16_NO_TAP_BARRIER
-                __syncthreads();
-#endif
-                cur ^= 1;
             }
             hb ^= 1;
         }
-        // the shortcut phase and the statistics epilogue below use halo buffer 0 / Bs buffer 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail requests
+        __syncthreads();
+        // the shortcut phase and the statistics epilogue below use halo buffer 0 / weight buffer 0
     }
     // ---- fused 1x1 shortcut (skip_connection of a ResBlock, unet.py:222,256): extra K chunks over the block's
     // raw input at the centre tap (see conv_igemm_f32.hip)
@@ -375,6 +433,11 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl, int kch = KC16) {
     const int Cin = d->C0 + d->C1;
     if (d->ksize != 3 || d->stride != 1 || d->pad != 1 || d->Ho != d->Hin || d->Wo != d->Win) return false;
     if (Cin % kch || d->C0 % kch || d->Cout % 128 || d->out_nchw) return false;
+    {   // the loader addresses both sources with 32-bit buffer offsets and an out-of-range sentinel for padding
+        const int64_t px = (int64_t)d->B * (d->ups ? d->Hin / 2 : d->Hin) * (d->ups ? d->Win / 2 : d->Win);
+        const int64_t cmax = d->C0 > d->C1 ? d->C0 : d->C1;
+        if (px * cmax * (d->src_f16 ? 2 : 4) >= (int64_t)1 << 31) return false;
+    }
     pl->BM = DDNM_F16_BM;
     if (HWo % pl->BM) return false;
     int tw = 32;
@@ -387,7 +450,7 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl, int kch = KC16) {
     int ks = 1;
     const int nchunks = Cin / kch;
     if (tiles < 192) {
-        ks = (int)((512 + tiles - 1) / tiles);
+        ks = (int)((DDNM_F16_KS_TARGET + tiles - 1) / tiles);
         if (ks > nchunks) ks = nchunks;
         if (ks > 16) ks = 16;
     }

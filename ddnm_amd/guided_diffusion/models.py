@@ -52,8 +52,10 @@ class _Attn:
 
 
 class Model:
-    def __init__(self, config, device=None):
+    def __init__(self, config, device=None, split16=None):
+        """`split16`: run the 3x3 / stride-1 layers on the split-fp16 kernel (None: the DDNM_CONV_F32 default above)."""
         self.config = config
+        self.split16 = SPLIT16 if split16 is None else bool(split16)
         m = config.model
         self.ch, self.out_ch, self.ch_mult = m.ch, m.out_ch, tuple(m.ch_mult)
         self.num_res_blocks = m.num_res_blocks
@@ -216,7 +218,7 @@ class Model:
             w[f"{n}.conv1.weight"] = ops.pack_conv_weight(g(f"{n}.conv1.weight"))
             w[f"{n}.conv2.weight"] = ops.pack_conv_weight(g(f"{n}.conv2.weight"))
             w[f"{n}.conv2.bias"] = g(f"{n}.conv2.bias")
-            if SPLIT16:
+            if self.split16:
                 # split-fp16 packing (fp32-grade products on the fp16 matrix pipe, ops.pack_conv_weight_s16); conv2 and
                 # its fused shortcut share an accumulator, hence one scale
                 w1, w2 = g(f"{n}.conv1.weight"), g(f"{n}.conv2.weight")
@@ -254,7 +256,7 @@ class Model:
         for lvl, (_, _, has_up, c) in self.up.items():
             if has_up:
                 w[f"up.{lvl}.upsample.conv.weight"] = ops.pack_conv_weight(g(f"up.{lvl}.upsample.conv.weight"))
-                if SPLIT16:
+                if self.split16:
                     wu = g(f"up.{lvl}.upsample.conv.weight")
                     su = ops.s16_weight_scale(wu)
                     w[f"up.{lvl}.upsample.conv.s16"] = (ops.pack_conv_weight_s16(wu, su), su, None)
