@@ -109,6 +109,10 @@ PROTOTYPES = {
     "ddnm_conv3x3_s16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_act_scale": (c_float, []),
+    "ddnm_conv_gather_s16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
+    "ddnm_conv_gather_s16_supported": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv_gather_s16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
+    "ddnm_conv_gather_s16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv16": (c_int32, [POINTER(Conv16Desc), c_void_p]),
     "ddnm_conv16_supported": (c_int32, [POINTER(Conv16Desc)]),
     "ddnm_conv16_fuses_fin": (c_int32, [POINTER(Conv16Desc)]),

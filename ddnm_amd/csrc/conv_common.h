@@ -199,6 +199,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
     }
 }
 
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+// fp32 x4 -> hi | lo fp16 halves of a split row: hi at dst, lo 32 halfs behind it (split-fp16 kernels: conv_igemm_f16.hip <.., SPLIT>, conv_gather_s16.hip)
+#ifndef DDNM_S16_ASCALE
+// Power-of-two pre-scale of the activation operand (undone by acc_scale): 1.  The MFMA honours fp16 subnormals, so the
+// absolute error of hi + lo is <= 2^-25 for |v| < 0.25 and <= 2^-22 |v| above: tensors whose typical magnitude is >= ~0.1
+// (every GroupNorm'd / swish'd activation and the residual stream of the network) are carried to fp32 grade, a tensor that
+// is uniformly ~0.02 keeps ~1e-6 and one that is uniformly ~2e-4 keeps ~1e-4.  A larger pre-scale would move that floor
+// down but trade away overflow margin (fp16 overflows at 65504 / scale): with 16 the randomly initialised 256^2 UNet of
+// bench.py, whose residual stream reaches several thousand, overflowed in its raw-operand launches (Downsample, proj_out).
+#define DDNM_S16_ASCALE 1.0f
+#endif
+__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {
+    v = v * DDNM_S16_ASCALE;
+    const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const half4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
+                     (_Float16)(v.w - (float)h.w)};
+    *reinterpret_cast<half4*>(dst) = h;
+    *reinterpret_cast<half4*>(dst + 32) = l;
+}
+
 __device__ __forceinline__ f32x4 gn_act(f32x4 v, const f32x4 gsc, const f32x4 gsh, int silu) {
     v = v * gsc + gsh;
     if (silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }

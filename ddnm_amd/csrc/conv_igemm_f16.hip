@@ -20,8 +20,6 @@
 //   per tap and wave: 16 (split form: 24) MFMAs between barriers.
 #include "conv_common.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // Build-time tile variants for probing (tools/conv16_ablate.py): -DDDNM_F16_KC=32 -DDDNM_F16_BM=512 is the 8-wave
@@ -40,24 +38,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int KC16 = DDNM_F16_KC;   // channels per chunk
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
-
-// fp32 x4 -> hi | lo fp16 halves of a split row: hi at dst, lo 32 halfs behind it (conv3x3_halo_f16_kernel<.., SPLIT>)
-#ifndef DDNM_S16_ASCALE
-// Power-of-two pre-scale of the activation operand (undone by acc_scale).  `lo` = rn16(v - hi) is a NORMAL fp16 number
-// for |16 v| >= 0.25; below that it loses bits one by one (the MFMA honours fp16 subnormals; the absolute error of
-// hi + lo stays <= 2^-25 / 16), so operands of magnitude >= 2^-6 -- every GroupNorm'd / residual-stream tensor of the
-// network -- keep the 2^-22 relative bound, and a tensor that is uniformly ~1e-4 still keeps ~1e-5.  fp16 overflow starts
-// at |v| = 4094, far above any activation of the network (a larger scale would trade that margin away).
-#define DDNM_S16_ASCALE 16.0f
-#endif
-__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {
-    v = v * DDNM_S16_ASCALE;
-    const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    const half4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
-                     (_Float16)(v.w - (float)h.w)};
-    *reinterpret_cast<half4*>(dst) = h;
-    *reinterpret_cast<half4*>(dst + 32) = l;
-}
 
 // SRC16 = the activation operand is already fp16 in HBM (written by ddnm_gn_apply_f16: GroupNorm affine +
 // swish applied ONCE per element instead of once per (output-channel tile x halo overlap) inside this kernel,

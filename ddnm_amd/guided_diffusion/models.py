@@ -204,6 +204,10 @@ class Model:
         dev = self.device
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
         w = {}
+
+        def s16(t):                 # split-fp16 packing of one weight tensor with its own scale
+            sc = ops.s16_weight_scale(t)
+            return (ops.pack_conv_weight_s16(t, sc), sc, None)
         for k in ("temb.dense.0", "temb.dense.1"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
         w["conv_in.weight"] = ops.pack_conv_weight(g("conv_in.weight"), cin_pad=CIN_PAD)
@@ -228,6 +232,8 @@ class Model:
                 w[f"{n}.conv1.s16"] = (ops.pack_conv_weight_s16(w1, s1), s1, None)
                 w[f"{n}.conv2.s16"] = (ops.pack_conv_weight_s16(w2, s2), s2,
                                        None if wsk is None else ops.pack_conv_weight_s16(wsk, s2))
+                if wsk is not None:
+                    w[f"{n}.nin_shortcut.s16"] = s16(wsk)          # un-fused form (8 x 8 level: gather kernel)
             # conv1 bias folded into the (concatenated) temb projection: h = conv1(.) + b1 + proj(temb)
             tw.append(g(f"{n}.temb_proj.weight"))
             tb.append(g(f"{n}.temb_proj.bias") + g(f"{n}.conv1.bias"))
@@ -246,6 +252,9 @@ class Model:
             w[f"{n}.norm.weight"], w[f"{n}.norm.bias"] = g(f"{n}.norm.weight"), g(f"{n}.norm.bias")
             wq = torch.cat([g(f"{n}.{p}.weight") for p in ("q", "k", "v")], 0)
             w[f"{n}.qkv.weight"] = ops.pack_conv_weight(wq)
+            if self.split16:
+                w[f"{n}.qkv.s16"] = s16(wq)
+                w[f"{n}.proj_out.s16"] = s16(g(f"{n}.proj_out.weight"))
             w[f"{n}.qkv.bias"] = torch.cat([g(f"{n}.{p}.bias") for p in ("q", "k", "v")], 0).contiguous()
             w[f"{n}.proj_out.weight"] = ops.pack_conv_weight(g(f"{n}.proj_out.weight"))
             w[f"{n}.proj_out.bias"] = g(f"{n}.proj_out.bias")
@@ -253,6 +262,8 @@ class Model:
             if has_down:
                 w[f"down.{lvl}.downsample.conv.weight"] = ops.pack_conv_weight(g(f"down.{lvl}.downsample.conv.weight"))
                 w[f"down.{lvl}.downsample.conv.bias"] = g(f"down.{lvl}.downsample.conv.bias")
+                if self.split16:
+                    w[f"down.{lvl}.downsample.conv.s16"] = s16(g(f"down.{lvl}.downsample.conv.weight"))
         for lvl, (_, _, has_up, c) in self.up.items():
             if has_up:
                 w[f"up.{lvl}.upsample.conv.weight"] = ops.pack_conv_weight(g(f"up.{lvl}.upsample.conv.weight"))
@@ -305,12 +316,17 @@ class Model:
         gn2 = self._gn(h, None, n + ".norm2")
         if rb.cin != rb.cout:
             B, H, W, _ = h.t.shape
-            if ops.conv_fuses_skip(B, H, W, rb.cout, rb.cout):
+            fuse = ops.conv_fuses_skip(B, H, W, rb.cout, rb.cout)
+            if (fuse and self.split16 and not ops.conv_runs_s16(B, H, W, rb.cout, rb.cout)
+                    and ops.conv_runs_s16_gather(B, H, W, rb.cout, rb.cout)):
+                fuse = False        # 8 x 8 level: two split-fp16 gather launches beat one fp32 MFMA launch with the fused shortcut
+            if fuse:
                 return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True,
                                   bias=w[n + ".conv2_plus_shortcut.bias"], skip=(x0, x1),
                                   skip_weight=w[n + ".nin_shortcut.fused"], emit_stats=True,
                                   weight_s16=w.get(n + ".conv2.s16"))
-            xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"])
+            xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"],
+                            weight_s16=w.get(n + ".nin_shortcut.s16"))
         else:
             assert x1 is None
             xs = x0
@@ -325,7 +341,8 @@ class Model:
         B, H, W, C = x.t.shape
         T = H * W
         gn = self._gn(x, None, n + ".norm")
-        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"],
+                         weight_s16=w.get(n + ".qkv.s16"))
         S = torch.empty(B, T, T, dtype=torch.float32, device=qkv.device)
         q, k, v = qkv.view(-1)[0:], qkv.view(-1)[C:], qkv.view(-1)[2 * C:]
         ops.bgemm(q, k, S, T, T, C, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B,
@@ -334,7 +351,8 @@ class Model:
         o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
         ops.bgemm(S, v, o, T, C, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B,
                   sA=(T * T, 0), sB=(T * 3 * C, 0), sC=(T * C, 0))
-        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
+        return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True,
+                          weight_s16=w.get(n + ".proj_out.s16"))
 
     def enable_graphs(self, two_streams=False):
         """Replay the forward from a captured hipGraph (ddnm_amd/graph.py)."""
@@ -383,7 +401,8 @@ class Model:
                 # F.pad(x, (0,1,0,1)) + 3x3 stride 2 (models.py:68-71): pad=0 on top/left, the
                 # bottom/right zero row/column comes from the loader's bounds check
                 hs.append(ops.conv2d(src, w[n + ".weight"], c, 3, bias=w[n + ".bias"], stride=2, pad=0,
-                                     out_hw=(src.t.shape[1] // 2, src.t.shape[2] // 2), emit_stats=True))
+                                     out_hw=(src.t.shape[1] // 2, src.t.shape[2] // 2), emit_stats=True,
+                                     weight_s16=w.get(n + ".s16")))
         h = hs[-1]
         h = self._resblock(self.mid[0], h, None, tproj)
         h = self._attn(self.mid[1], h)

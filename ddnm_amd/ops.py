@@ -151,7 +151,18 @@ def conv_runs_s16(B, H, W, cin, cout, ups=False):
     return _lib.lib().ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1
 
 
+def conv_runs_s16_gather(B, H, W, cin, cout, ksize=3, stride=1):
+    """True when a conv of this INPUT shape takes the gather form of the split-fp16 arithmetic (no fused shortcut)."""
+    if _NO_S16_GATHER:
+        return False
+    d = ConvDesc()
+    d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, H, W, cin, 0, cout
+    d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, (ksize // 2 if stride == 1 else 0), H // stride, W // stride
+    return _lib.lib().ddnm_conv_gather_s16_supported(ctypes.byref(d)) == 1
+
+
 _S16_ACT_SCALE = None
+_NO_S16_GATHER = _os.environ.get("DDNM_NO_S16_GATHER") == "1"      # A/B switch: gather-form launches stay on the fp32 MFMA kernel
 
 
 def _s16_act_scale():
@@ -234,7 +245,10 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     f16, f16_1x1 = False, False
     s16 = (weight_s16 is not None and weight_f16 is None and ksize == 3 and stride == 1
            and (skip is None or weight_s16[2] is not None) and L.ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1)
-    if s16:
+    # ... and the per-tap gather form of the same arithmetic for 1x1 / strided / 8x8-level launches (no fused shortcut)
+    s16g = (not s16 and weight_s16 is not None and weight_f16 is None and skip is None and not _NO_S16_GATHER
+            and L.ddnm_conv_gather_s16_supported(ctypes.byref(d)) == 1)
+    if s16 or s16g:
         d.weight = weight_s16[0].data_ptr()
         d.acc_scale = 1.0 / (float(weight_s16[1]) * _s16_act_scale())
     if weight_f16 is not None:
@@ -286,6 +300,9 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         fn_run, fn_tiles, fn_ws = L.ddnm_conv3x3_f16_f32, L.ddnm_conv3x3_f16_stats_tiles, L.ddnm_conv3x3_f16_workspace_floats
     elif s16:
         fn_run, fn_tiles, fn_ws = L.ddnm_conv3x3_s16_f32, L.ddnm_conv3x3_s16_stats_tiles, L.ddnm_conv3x3_s16_workspace_floats
+    elif s16g:
+        fn_run, fn_tiles, fn_ws = (L.ddnm_conv_gather_s16_f32, L.ddnm_conv_gather_s16_stats_tiles,
+                                   L.ddnm_conv_gather_s16_workspace_floats)
     else:
         fn_run, fn_tiles, fn_ws = L.ddnm_conv2d_f32, L.ddnm_conv2d_f32_stats_tiles, L.ddnm_conv2d_f32_workspace_floats
     stats, tiles = None, 0
@@ -307,6 +324,8 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
             variant = "conv3x3_halo_f16<256x128>"
         elif s16:
             variant = "conv3x3_halo_s16<256x128>"
+        elif s16g:
+            variant = "conv_gather_s16"
         else:
             tn = L.ddnm_conv2d_f32_tile_n(ctypes.byref(d))
             kind = "conv3x3_halo_f32" if (ksize == 3 and stride == 1) else "conv_gather_f32"

@@ -137,6 +137,17 @@ int64_t ddnm_conv3x3_s16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv3x3_s16_stats_tiles(const ddnm_conv_desc* d);
 float ddnm_conv3x3_s16_act_scale(void);   /* power of two the kernel multiplies activations with before splitting them */
 
+/* The same arithmetic for the layers the 3x3 halo kernel does not take, as a per-tap gather (csrc/conv_gather_s16.hip):
+ * Downsample's 3x3 stride 2 with (0,1,0,1) padding (guided_diffusion/models.py:61-71), the 1x1 convolutions of the
+ * attention blocks and un-fused nin_shortcut (models.py:109,143-162), and 3x3 / stride 1 on the 8 x 8 level.  Same
+ * descriptor, weight packing and acc_scale as ddnm_conv3x3_s16_f32 (ksize 1 or 3, stride 1 or 2, pad as given; GroupNorm
+ * prologue, concat, bias / badd / residual, statistics, split-K); no fused shortcut.
+ * Needs C0 % 32 == 0, C1 % 32 == 0, Cout % 64 == 0, Ho*Wo % 64 == 0 (else: ddnm_conv2d_f32). */
+int ddnm_conv_gather_s16_f32(const ddnm_conv_desc* d, void* stream);
+int ddnm_conv_gather_s16_supported(const ddnm_conv_desc* d);
+int64_t ddnm_conv_gather_s16_workspace_floats(const ddnm_conv_desc* d);
+int ddnm_conv_gather_s16_stats_tiles(const ddnm_conv_desc* d);
+
 /* 1x1 convolution with fp16 MFMA operands, fp32 accumulate / output: the attention blocks' qkv and proj_out
  * Conv1d(k=1) and un-fused 1x1 shortcuts of the `use_fp16` torso (guided_diffusion/unet.py:222,283-289,301-308).
  * Same descriptor with ksize = 1, stride 1, pad 0; `weight` = (O,1,I)-packed fp16; src fp32, or fp16 with src_f16 = 1

@@ -107,10 +107,10 @@ def test_split_kernel_is_at_least_as_close_to_fp64_as_the_fp32_kernel(case):
     assert ((a16.t - a32.t).norm() / a32.t.norm()).item() < 1.5e-6
 
 
-@pytest.mark.parametrize("wscale,ascale", [(40.0, 1.5), (3e-5, 1.5), (0.05, 300.0), (0.05, 0.02)])
+@pytest.mark.parametrize("wscale,ascale", [(40.0, 1.5), (3e-5, 1.5), (0.05, 300.0), (0.05, 8000.0), (0.05, 0.15)])
 def test_split_kernel_badly_scaled_operands(wscale, ascale):
-    # weights far from 1 are brought into fp16 range by the per-launch power of two; activations are pre-scaled by a fixed
-    # 16: large ones stay far below the fp16 maximum, small ones keep a normal (or nearly normal) `lo` half
+    # weights far from 1 are brought into fp16 range by the per-launch power of two; activations are split as they are:
+    # large ones (up to the fp16 maximum, 65504) and ordinary ones are carried to fp32 grade
     t = _make(2, 128, 0, 128, 32, 0, 0, 0, 0, seed=3, wscale=wscale, ascale=ascale)
     t["bias"].zero_()
     e = _errors(t)
@@ -118,17 +118,18 @@ def test_split_kernel_badly_scaled_operands(wscale, ascale):
     assert e[True][0] <= 1.25 * e[False][0] + 2e-8
 
 
-def test_split_kernel_uniformly_tiny_operand_degrades_gracefully():
-    # a tensor that is ~2e-4 everywhere sits in the subnormal range of `lo`: the absolute error stays <= 2^-29 per
-    # element, the relative error of the result grows to ~1e-5 (documented domain: csrc/conv_igemm_f16.hip)
-    t = _make(2, 128, 0, 128, 32, 0, 0, 0, 0, seed=3, wscale=0.05, ascale=2e-4)
+@pytest.mark.parametrize("ascale,bound", [(0.02, 3e-6), (2e-4, 3e-4)])
+def test_split_kernel_uniformly_tiny_operand_degrades_gracefully(ascale, bound):
+    # a tensor that is tiny everywhere sits in the subnormal range of `lo`: the absolute error stays <= 2^-25 per
+    # element, the relative error of the result grows accordingly (documented domain: csrc/conv_common.h)
+    t = _make(2, 128, 0, 128, 32, 0, 0, 0, 0, seed=3, wscale=0.05, ascale=ascale)
     t["bias"].zero_()
     e = _errors(t)
-    assert e[True][0] < 2e-5, e[True][0]
+    assert e[True][0] < bound, e[True][0]
 
 
 def test_fp16_mfma_honours_subnormal_inputs():
-    # small operands rely on it: lo = rn16(16 v - hi) is subnormal for |16 v| < 0.25
+    # small operands rely on it: lo = rn16(v - hi) is subnormal for |v| < 0.25
     from ddnm_amd import ops
     sa = ops._s16_act_scale()
     t = _make(1, 128, 0, 128, 16, 0, 0, 0, 0, seed=5, ascale=1.0)
@@ -145,7 +146,8 @@ def test_shapes_outside_the_split_kernel_fall_back_to_fp32_mfma():
     from ddnm_amd import ops
     assert not ops.conv_runs_s16(8, 8, 8, 512, 512)             # 8 x 8 level: no 256-pixel tile inside an image
     assert not ops.conv_runs_s16(2, 32, 32, 128, 96)            # Cout % 128
-    t = _make(2, 512, 0, 512, 8, 0, 1, 1, 0)
+    t = _make(2, 512, 0, 160, 8, 0, 1, 1, 0)                    # Cout % 64: neither the halo nor the gather form
+    assert not ops.conv_runs_s16_gather(2, 8, 8, 512, 160)
     e = _errors(t)
     assert e[True][0] == e[False][0]                            # same kernel ran both times
 
@@ -164,3 +166,65 @@ def test_celeba_model_split_vs_fp32_mfma_paths():
     t = torch.tensor([999.0, 500.0, 37.0, 0.0], device=DEV)
     ea, eb = a(x, t), b(x, t)
     assert ((ea - eb).double().norm() / eb.double().norm()).item() < 3e-6
+
+
+# ------------------------------------------------------------------ gather form (1x1, strided, 8 x 8 level)
+# B, C0, C1, Cout, H, ksize, stride, gn, gn_silu, res
+GATHER_CASES = [
+    (2, 128, 0, 128, 32, 3, 2, 0, 0, 0),      # Downsample: pad (0,1,0,1), stride 2 (models.py:61-71)
+    (2, 256, 0, 256, 16, 3, 2, 0, 0, 0),
+    (2, 512, 0, 1536, 16, 1, 1, 1, 0, 0),     # attention qkv: GroupNorm affine without swish
+    (2, 512, 0, 512, 16, 1, 1, 0, 0, 1),      # attention proj_out: residual
+    (2, 256, 256, 256, 16, 1, 1, 0, 0, 0),    # un-fused nin_shortcut over a concat
+    (8, 512, 0, 512, 8, 3, 1, 1, 1, 1),       # 8 x 8 level: M tile = one image, split-K
+    (4, 512, 512, 512, 8, 3, 1, 1, 1, 0),
+    (1, 160, 0, 192, 8, 3, 1, 1, 1, 0),       # Cout = 3 x 64, Cin = 5 chunks
+]
+
+
+@pytest.mark.parametrize("case", GATHER_CASES)
+def test_gather_split_kernel_vs_fp64_and_fp32_kernel(case):
+    from ddnm_amd import ops
+    B, C0, C1, Cout, H, k, stride, gn, silu, res = case
+    g = torch.Generator(device=DEV).manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    cin = C0 + C1
+    Ho = H // stride
+    a, b = rn(B, H, H, C0) * 1.5, (rn(B, H, H, C1) * 1.5 if C1 else None)
+    w = rn(Cout, cin, k, k) / (k * cin ** 0.5)
+    bias = rn(Cout)
+    sc, sh = (rn(B, cin) * 0.3 + 1.0, rn(B, cin) * 0.3) if gn else (None, None)
+    r = rn(B, Ho, Ho, Cout) * 2.0 if res else None
+    assert ops.conv_runs_s16_gather(B, H, H, cin, Cout, ksize=k, stride=stride)
+    assert not (k == 3 and stride == 1 and ops.conv_runs_s16(B, H, H, cin, Cout))
+    # fp64 evaluation
+    x = (a if b is None else torch.cat([a, b], 3)).double()
+    if gn:
+        x = x * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]
+        if silu:
+            x = x * torch.sigmoid(x)
+    x = x.permute(0, 3, 1, 2)
+    if stride == 2:
+        x = F.pad(x, (0, 1, 0, 1))
+        y = F.conv2d(x, w.double(), bias.double(), stride=2)
+    else:
+        y = F.conv2d(x, w.double(), bias.double(), padding=k // 2)
+    y = y.permute(0, 2, 3, 1)
+    if res:
+        y = y + r.double()
+    w32 = ops.pack_conv_weight(w)
+    s = ops.s16_weight_scale(w)
+    errs = {}
+    for split in (False, True):
+        act = ops.conv2d(a, w32, Cout, k, src1=b, bias=bias, res=r, gn=None if not gn else (sc, sh), gn_silu=bool(silu),
+                         stride=stride, pad=(0 if stride == 2 else k // 2), out_hw=(Ho, Ho), emit_stats=True,
+                         weight_s16=(ops.pack_conv_weight_s16(w, s), s, None) if split else None)
+        o = act.t.double()
+        errs[split] = ((o - y).norm() / y.norm()).item()
+        if act.stats is not None:
+            st = act.stats.view(B, act.tiles, -1, 2).double().sum(1)
+            s1, s2 = o.sum((1, 2)), (o * o).sum((1, 2))
+            assert ((st[..., 0] - s1).abs().max() / s1.abs().max()).item() < 2e-6
+            assert ((st[..., 1] - s2).abs().max() / s2.abs().max()).item() < 2e-6
+    assert errs[True] < 8e-7, errs
+    assert errs[True] <= 1.25 * errs[False] + 2e-8, errs
