@@ -32,7 +32,8 @@ BDB=$(find gpurun_out/prof_bench -name "*.db" | head -1); ADB=$(find gpurun_out/
 python tools/prof_summary.py $BDB gpurun_out/${R}_bench_kernel_stats.md > /dev/null; head -12 gpurun_out/${R}_bench_kernel_stats.md
 python tools/prof_summary.py $ADB gpurun_out/${R}_adm_fp16_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_adm_fp16_forward_kernel_stats.md
 python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
-PMC_AFTER_MARKER=finalize_psnr python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+# dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., false, true)
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>' python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
 # bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
 # (profiles/*_pmc_dominant_kernel.json, profiles/*_adm_pmc_conv16.json): install this run's summaries first

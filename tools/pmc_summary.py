@@ -73,6 +73,18 @@ def main(root, out_json, out_md, stats_db=None):
                 "launch writes 266240 KiB = output 262144 KiB + GN partials 4096 KiB)",
     }
     res.update(lds)
+    # effective shader clock of the same launches: GRBM_GUI_ACTIVE / 8 XCDs / launch duration (kernel trace of the MFMA pass)
+    try:
+        import glob
+        kt = pd.read_csv(glob.glob(f"{root}/pmc_mfma/*kernel_trace.csv")[0])[["Dispatch_Id", "Start_Timestamp", "End_Timestamp"]]
+        mk = m.merge(kt, on="Dispatch_Id")
+        ns = (mk.End_Timestamp - mk.Start_Timestamp).astype(float)
+        res["effective_clock_ghz"] = float((mk.GRBM_GUI_ACTIVE / 8.0).sum() / ns.sum())
+        res["effective_clock_note"] = "sum(GRBM_GUI_ACTIVE / 8) / sum(launch duration) over the launches of the MFMA pass; " \
+                                      "2.4 GHz nominal -- lower = power limiting (MI355X_MICROARCH.md)"
+    except Exception as e:      # noqa: BLE001
+        res["effective_clock_ghz"] = None
+        res["effective_clock_note"] = f"not available: {e!r}"
     json.dump(res, open(out_json, "w"), indent=1)
     lines = ["# PMC passes on the dominant kernel (rocprofv3 --pmc, separate runs)", "",
              "```", json.dumps(res, indent=1), "```", "", "| grid (threads) | launches | MFMA busy | FETCH MB (x2) | WRITE MB |",
