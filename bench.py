@@ -367,6 +367,8 @@ def main():
                     help="default c2 run at 1 GPU: do not append the short c3 / c4 / c5 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-path", action="store_true",
+                    help="skip the one-pass measurement of the all-fp32-MFMA engine (kernel-trace profiles of the headline path)")
     args = ap.parse_args()
 
     from ddnm_amd import _lib
@@ -515,7 +517,7 @@ def main():
         except Exception as e:    # noqa: BLE001
             ops.set_kernel_timer(None)
             line["roofline"] = {"error": repr(e)}
-    if world == 1 and getattr(model, "split16", False) and not args.no_roofline:
+    if world == 1 and getattr(model, "split16", False) and not args.no_roofline and not args.no_side_path:
         # the same restoration (same noise) on the all-fp32-MFMA engine: its speed, and how far the two results are apart
         try:
             model32 = Model(cfg, device=dev, split16=False)

@@ -19,22 +19,27 @@ timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1 || { tai
 tail -1 gpurun_out/smoke.log
 if [ "$SKIP_TESTS" != "1" ]; then timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee gpurun_out/${R}_gpu_tests.log; fi
 cd /tmp
-rm -rf /root/repo/gpurun_out/prof_bench /root/repo/gpurun_out/prof_adm16 /root/repo/gpurun_out/prof_c2fwd /root/repo/gpurun_out/pmc_c2 /root/repo/gpurun_out/pmc16
-timeout -k 10 420 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-workloads > /root/repo/gpurun_out/prof_bench.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_adm16 -o adm -- python /root/repo/tools/adm_fwd.py 5 > /root/repo/gpurun_out/prof_adm16.log 2>&1
+# raw rocprofv3 output (databases, per-dispatch counter tables: > 64 MiB in all) stays under /tmp on the box: gpurun copies
+# gpurun_out/ back only while it is small, and only the summaries are wanted
+RAW=/tmp/ddnm_prof
+rm -rf $RAW; mkdir -p $RAW
+timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $RAW/prof_bench -o c2 -- python /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra-workloads --no-side-path > /root/repo/gpurun_out/prof_bench.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $RAW/prof_c2fwd -o fw -- python /root/repo/tools/forward_once.py 5 > /root/repo/gpurun_out/prof_c2fwd.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $RAW/prof_adm16 -o adm -- python /root/repo/tools/adm_fwd.py 5 > /root/repo/gpurun_out/prof_adm16.log 2>&1
 for k in mfma fetch write; do
   case $k in mfma) C="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
-  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d /root/repo/gpurun_out/pmc_c2/pmc_$k -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc_c2_$k.log 2>&1
-  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d /root/repo/gpurun_out/pmc16/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16_$k.log 2>&1
+  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc_c2/pmc_$k -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc_c2_$k.log 2>&1
+  timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc16/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16_$k.log 2>&1
 done
 cd /root/repo
-BDB=$(find gpurun_out/prof_bench -name "*.db" | head -1); ADB=$(find gpurun_out/prof_adm16 -name "*.db" | head -1)
+BDB=$(find $RAW/prof_bench -name "*.db" | head -1); ADB=$(find $RAW/prof_adm16 -name "*.db" | head -1)
 python tools/prof_summary.py $BDB gpurun_out/${R}_bench_kernel_stats.md > /dev/null; head -12 gpurun_out/${R}_bench_kernel_stats.md
 python tools/prof_summary.py $ADB gpurun_out/${R}_adm_fp16_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_adm_fp16_forward_kernel_stats.md
+python tools/prof_summary.py $(find $RAW/prof_c2fwd -name "*.db" | head -1) gpurun_out/${R}_celeba_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_celeba_forward_kernel_stats.md
 python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
 # dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., false, true)
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>' python tools/pmc_summary.py gpurun_out/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py gpurun_out/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
 # bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
 # (profiles/*_pmc_dominant_kernel.json, profiles/*_adm_pmc_conv16.json): install this run's summaries first
 cp gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md profiles/
