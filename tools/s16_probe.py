@@ -110,7 +110,7 @@ def run(t, split):
 
 VARIANTS = {
     "base": [],
-    "regw": "tools/_build/conv_igemm_f16_regw.hip",       # a saved copy of the source with register-staged weights
+    # a path instead of a flag list = another source file (e.g. a saved copy of an older kernel under tools/_build/)
     "ks256": ["-DDDNM_F16_KS_TARGET=256"], "ks384": ["-DDDNM_F16_KS_TARGET=384"], "ks768": ["-DDDNM_F16_KS_TARGET=768"],
     "nobar": ["-DDDNM_PROBE16_NO_TAP_BARRIER"],           # wrong results: no barrier per tap
     "nobload": ["-DDDNM_PROBE16_NO_BLOAD"],               # wrong results: no weight loads
