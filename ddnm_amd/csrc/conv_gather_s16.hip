@@ -10,8 +10,9 @@
 //
 // Workgroup 256 threads = 4 waves (2 x 2), tile 128 x 128 or 64 x 64; per (chunk, tap) step the A tile [BM][32 channels]
 // is gathered straight from global memory through registers -- GroupNorm affine (+ swish) applied, split into
-// [hi 32 | lo 32], 144-byte LDS row pitch (conflict-free ds_read_b128), requested one step ahead -- and the B tile
-// [BN][hi 32 | lo 32] arrives by LDS-DMA two steps ahead (unpadded swizzled image, three buffers, counted `vmcnt`).
+// [hi 32 | lo 32], 144-byte LDS row pitch (conflict-free ds_read_b128), requested TWO steps ahead (two register sets) --
+// and the B tile [BN][hi 32 | lo 32] arrives by LDS-DMA two steps ahead (unpadded swizzled image, three buffers); all
+// requests are counted (`s_waitcnt vmcnt(N)`, raw barriers): these launches are chains of L2 / HBM round trips.
 // Split-K over channel chunks for launches that cannot fill the chip.
 #include "conv_common.h"
 
@@ -69,41 +70,47 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
                                                      so + (unsigned)j * 32u * w_rowlen, 0, 0);
     };
 
-    f32x4 a_st[AR];
-    f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
-    unsigned a_valid = 0;
+    // ---- A tile: gathered through registers TWO steps ahead (two register sets used in turn).  Buffer loads with an
+    // out-of-range offset for padding (the load returns zero) and GroupNorm vectors fetched unconditionally (a dummy
+    // address without GroupNorm): every call issues EXACTLY AR + 2 requests per wave, so the loop can leave a whole younger
+    // step in flight behind the tile it waits for (`s_waitcnt vmcnt(N)` needs exact request counts).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned AOOB = 0x80000000u;          // every tensor here is < 2 GB (checked by the host)
     const bool has_gn = d.gn_scale != nullptr;
+    const __amdgpu_buffer_rsrc_t r_s0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.src0), 0, (unsigned)d.B * p.Hs * p.Ws * d.C0 * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_s1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(d.C1 > 0 ? d.src1 : d.src0), 0, (unsigned)d.B * p.Hs * p.Ws * (d.C1 > 0 ? d.C1 : d.C0) * 4u, 0x00020000);
+    const float* const gn_sc = has_gn ? d.gn_scale + (size_t)img * p.Cin + c4 * 4 : reinterpret_cast<const float*>(d.weight);
+    const float* const gn_sh = has_gn ? d.gn_shift + (size_t)img * p.Cin + c4 * 4 : reinterpret_cast<const float*>(d.weight);
+    f32x4 a_st0[AR], a_st1[AR];
+    f32x4 gsc0, gsh0, gsc1, gsh1;
+    unsigned a_valid0 = 0, a_valid1 = 0;
 
-    auto prefetch_a = [&](int it) {
+    auto prefetch_a = [&](int it, f32x4 (&a_st)[AR], f32x4& gsc, f32x4& gsh, unsigned& a_valid) {
         const int chunk = it / p.ntaps, tap = it - chunk * p.ntaps;
         const int ky = tap / d.ksize, kx = tap - ky * d.ksize;
         const int cb = chunk * GS_KC;
-        const float* src;
-        int cs, coff;
-        if (cb < d.C0) { src = d.src0; cs = d.C0; coff = cb; }
-        else { src = d.src1; cs = d.C1; coff = cb - d.C0; }
+        const bool first = cb < d.C0;
+        const unsigned cs = first ? d.C0 : d.C1, coff = first ? cb : cb - d.C0;
+        const __amdgpu_buffer_rsrc_t r_s = first ? r_s0 : r_s1;            // wave-uniform: a scalar select, no branch
         a_valid = 0;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
+            // branch-free: a divergent `ok ? load : zero` makes hipcc duplicate the load into both arms and guard the
+            // second one with a full `vmcnt(0)` (same destination registers), which drains the requests in flight
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
-                v = *reinterpret_cast<const f32x4*>(src + ((size_t)(img * p.Hs + sy) * p.Ws + sx) * cs + coff + c4 * 4);
-                a_valid |= 1u << i;
-            }
-            a_st[i] = v;
+            const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+            const unsigned vo = (((unsigned)((img * p.Hs + sy) * p.Ws + sx) * cs + c4 * 4) * 4u) | (ok ? 0u : AOOB);
+            a_st[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_s, vo, coff * 4u, 0));
+            a_valid |= ok ? (1u << i) : 0u;
         }
-        // every step, not only at tap 0: a conditional load merges with the old value through register copies, which
-        // the compiler guards with a full `vmcnt(0)` right here -- draining the weight tiles in flight
-        if (has_gn) {
-            gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + c4 * 4);
-            gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + c4 * 4);
-        }
+        gsc = *reinterpret_cast<const f32x4*>(gn_sc + (has_gn ? cb : 0));
+        gsh = *reinterpret_cast<const f32x4*>(gn_sh + (has_gn ? cb : 0));
     };
 
-    auto stage_a = [&]() {
+    auto stage_a = [&](f32x4 (&a_st)[AR], const f32x4& gsc, const f32x4& gsh, unsigned a_valid) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             f32x4 v = a_st[i];
@@ -128,24 +135,26 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
     const int b_frag = ((wn * NT * 32 + (lane & 31)) * 128) + ((((lane >> 5) ^ (((lane & 31) >> 1) & 7))) << 4);
 
     // Per step:  [barrier: As and the buffer of W(it-1) are free | A(it): registers -> GroupNorm / split -> LDS |
-    //             my pieces of W(it) landed | barrier | request A(it+1) (registers) and W(it+2) (LDS-DMA) | MFMA(it)].
-    // Requests beyond the last step are clamped to it (re-fetching a tile nobody reads keeps the `vmcnt` bookkeeping
-    // uniform): behind W(it) exactly the BR requests of W(it+1) are in flight when it is awaited.
+    //             my pieces of W(it) landed | barrier | request A(it+2) (registers) and W(it+2) (LDS-DMA) | MFMA(it)].
+    // Requests beyond the last step are clamped to it (re-fetching what nobody reads keeps the `vmcnt` bookkeeping
+    // uniform): behind W(it) exactly the AR + 2 + BR requests of step it+1 are in flight when it is awaited.
     if (it_begin < it_end) {
         const int last = it_end - 1;
-        prefetch_a(it_begin);
+        auto clampi = [&](int q) { return q < last ? q : last; };
+        prefetch_a(it_begin, a_st0, gsc0, gsh0, a_valid0);
         issue_b(it_begin, 0);
-        issue_b(it_begin + 1 < last ? it_begin + 1 : last, 1);
+        prefetch_a(clampi(it_begin + 1), a_st1, gsc1, gsh1, a_valid1);
+        issue_b(clampi(it_begin + 1), 1);
         int cur = 0;
-        for (int it = it_begin; it < it_end; ++it) {
+        auto step = [&](int it, f32x4 (&a_st)[AR], f32x4& gsc, f32x4& gsh, unsigned& a_valid) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            stage_a();
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
+            stage_a(a_st, gsc, gsh, a_valid);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AR + 2 + BR) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (it + 1 < it_end) prefetch_a(it + 1);
-            issue_b(it + 2 < last ? it + 2 : last, cur >= 1 ? cur - 1 : NWB - 1);
+            prefetch_a(clampi(it + 2), a_st, gsc, gsh, a_valid);
+            issue_b(clampi(it + 2), cur >= 1 ? cur - 1 : NWB - 1);
             __builtin_amdgcn_sched_barrier(0);
             const char* bf = Bs + cur * WTILE;
 #pragma unroll
@@ -175,7 +184,16 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
                     for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
             }
             cur = cur == NWB - 1 ? 0 : cur + 1;
+        };
+        // pairs in the loop, an odd last step behind it: with `if (it + 1 < it_end) step(..)` inside, hipcc sees a back
+        // edge with only one step's requests in flight and waits for the A registers with `vmcnt(BR)` -- one step of
+        // lookahead instead of two
+        int it = it_begin;
+        for (; it + 1 < it_end; it += 2) {
+            step(it, a_st0, gsc0, gsh0, a_valid0);
+            step(it + 1, a_st1, gsc1, gsh1, a_valid1);
         }
+        if (it < it_end) step(it, a_st0, gsc0, gsh0, a_valid0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail requests
     }
     __syncthreads();               // the statistics epilogue reuses As
@@ -194,6 +212,11 @@ static bool plan_gs(const ddnm_conv_desc* d, PlanGS* pl) {
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return false;
     if (d->C0 <= 0 || d->C0 % GS_KC || d->C1 % GS_KC || d->out_nchw || d->src_f16 || d->skip0) return false;
     if (d->Cout % 64 || HWo % 64) return false;
+    {   // the loader addresses both sources with 32-bit buffer offsets and an out-of-range sentinel for padding
+        const int64_t px = (int64_t)d->B * (d->ups ? d->Hin / 2 : d->Hin) * (d->ups ? d->Win / 2 : d->Win);
+        const int64_t cmax = d->C0 > d->C1 ? d->C0 : d->C1;
+        if (px * cmax * 4 >= (int64_t)1 << 31) return false;
+    }
     const int nchunks = Cin / GS_KC;
     int tile = 2;
     if (HWo % 128 == 0 && d->Cout % 128 == 0) {

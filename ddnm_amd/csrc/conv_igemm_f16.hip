@@ -275,7 +275,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     // request W(s+2) into it | MFMA(s)].  Halo: double-buffered -- the next chunk's halo is loaded in two halves
     // (taps 0 and 3) and converted / GroupNorm'd / written to the OTHER halo buffer at taps 3 and 6, between MFMA
     // batches, so a chunk boundary costs nothing (re-staging it between two barriers used to be 28 % of the kernel).
-#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
+    // Static priority for one of the two waves that share a SIMD (waves w and w + 4; MI355X_MICROARCH.md): the pair stops
+    // competing for the matrix pipe in phase, the low-priority wave fills the other's barrier / fragment-read gaps.
+    // Split form: +2.4 ... 2.9 % on the 256^2 layers, nothing elsewhere (tools/s16_probe.py vtime base prio_half); no
+    // effect was ever measured for the fp16-operand form, which keeps the default.
+#ifndef DDNM_PROBE_NO_SETPRIO
+    if (SPLIT && wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: the same for every form
     if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
 #endif
     if (c_begin < c_end) {
