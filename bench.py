@@ -43,6 +43,31 @@ T_SAMPLING = 100
 BATCH_PER_GPU = 8
 
 
+def precision_check(dev):
+    """One seeded layer of the headline UNet (128 -> 128 @128^2, B = 2, GroupNorm affine + swish prologue, bias, residual)
+    evaluated in fp64 by torch on the GPU and by the two convolution engines through the C ABI: relative L2 error of the
+    split-fp16 kernel (ddnm_conv3x3_s16_f32) and of the fp32 MFMA kernel (ddnm_conv2d_f32) against fp64."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator(device=dev).manual_seed(2024)
+    rn = lambda *sh: torch.randn(*sh, device=dev, generator=g)  # noqa: E731
+    B, C, H = 2, 128, 128
+    a, w, bias = rn(B, H, H, C) * 1.5, rn(C, C, 3, 3) / (3.0 * C ** 0.5), rn(C)
+    sc, sh, r = rn(B, C) * 0.3 + 1.0, rn(B, C) * 0.3, rn(B, H, H, C) * 2.0
+    x = a.double() * sc.double()[:, None, None, :] + sh.double()[:, None, None, :]
+    x = (x * torch.sigmoid(x)).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    w32, scale = ops.pack_conv_weight(w), ops.s16_weight_scale(w)
+    s16 = (ops.pack_conv_weight_s16(w, scale), scale, None)
+    out = {}
+    for name, ws in (("split16", s16), ("f32_mfma", None)):
+        o = ops.conv2d(a, w32, C, 3, bias=bias, res=r, gn=(sc, sh), gn_silu=True, weight_s16=ws)
+        out[name] = float((o.double() - y).norm() / y.norm())
+    return {"layer": "3x3 128->128 @128x128, B=2, GroupNorm affine + swish, bias, residual (seeded)",
+            "rel_l2_error_vs_fp64": out,
+            "note": "fp64 = torch on the same GPU; both engines through the C ABI; tests/test_gpu_s16.py holds 16 more layer forms"}
+
+
 def baseline_metric():
     """The headline metric's name exactly as BASELINE.json spells it."""
     try:
@@ -517,6 +542,11 @@ def main():
         except Exception as e:    # noqa: BLE001
             ops.set_kernel_timer(None)
             line["roofline"] = {"error": repr(e)}
+    if rank == 0 and getattr(model, "split16", False) and not args.no_roofline:
+        try:
+            line["precision_check"] = precision_check(dev)
+        except Exception as e:    # noqa: BLE001
+            line["precision_check"] = {"error": repr(e)}
     if world == 1 and getattr(model, "split16", False) and not args.no_roofline and not args.no_side_path:
         # the same restoration (same noise) on the all-fp32-MFMA engine: its speed, and how far the two results are apart
         try:
