@@ -105,20 +105,25 @@ def cpu_baseline(cfg, sd, budget_s=90.0):
         avail = os.cpu_count() or 1
     mcfg, msd = cases.celeba_net("mid")
     mnet = unet_celeba.Net(msd, mcfg)
-    mx, mt = cases.forward_inputs(mcfg, 1)
-    best = (None, 1e30)
-    for nt in (8, 16, 32, 64, 128):
-        if nt > avail:
-            break
-        torch.set_num_threads(nt)
-        mnet(mx, mt)
-        t0 = time.perf_counter()
-        for _ in range(3):
+
+    def calibrate(batch):
+        """Best intra-op thread count for forwards of this batch size (reduced UNet; ATen's CPU convolutions parallelise
+        differently over batch 1 and batch 8, so each timed batch gets its own calibration)."""
+        mx, mt = cases.forward_inputs(mcfg, batch)
+        best = (None, 1e30)
+        for nt in (8, 16, 32, 64, 128):
+            if nt > avail:
+                break
+            torch.set_num_threads(nt)
             mnet(mx, mt)
-        dt = (time.perf_counter() - t0) / 3
-        if dt < best[1]:
-            best = (nt, dt)
-    threads = best[0] or min(avail, 8)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                mnet(mx, mt)
+            dt = (time.perf_counter() - t0) / 2
+            if dt < best[1]:
+                best = (nt, dt)
+        return best[0] or min(avail, 8)
+    threads = calibrate(1)
     torch.set_num_threads(threads)
     kind = "port"
     net = unet_celeba.Net(sd, cfg)
@@ -159,9 +164,13 @@ def cpu_baseline(cfg, sd, budget_s=90.0):
                      f"logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}; `b8_value`: the workload's own batch "
                      "of 8 for 3 reverse steps, same extrapolation"}
     try:
+        threads8 = calibrate(BATCH_PER_GPU)
+        torch.set_num_threads(threads8)
+        net(torch.zeros(BATCH_PER_GPU, 3, 256, 256), torch.full((BATCH_PER_GPU,), 990.0))      # warm-up at this batch
         dt8 = timed(BATCH_PER_GPU, 3)
         out["b8_value"] = BATCH_PER_GPU / (dt8 / 3 * T_SAMPLING)
         out["b8_seconds_for_3_steps"] = round(dt8, 2)
+        out["b8_cores"] = threads8
     except Exception as e:    # noqa: BLE001
         out["b8_value"] = None
         out["b8_error"] = repr(e)
@@ -311,23 +320,34 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
             kname, r = max(summ.items(), key=lambda kv: kv[1]["ms"])
             total_ms = sum(v["ms"] for v in summ.values())
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            # algorithmic HBM bytes of the same launches (fp16 tensors: input [+ shortcut input] + weights + output
+            # [+ residual], every operand once) -- what `traffic` (PMC) is to be compared with
+            alg = []
+            for (variant, _, _, _), (b_, ho, wo, cin, cout, k, stride, ups, skipc, _, has_res) in zip(timer.records, timer.shapes):
+                if variant == kname:
+                    pix_in = b_ * ho * wo // (4 if ups else 1)
+                    alg.append(2.0 * (pix_in * cin + b_ * ho * wo * skipc + cout * (k * k * cin + skipc)
+                                      + b_ * ho * wo * cout * (2 if has_res else 1)))
             # HBM traffic / MFMA-busy / rocprofv3 launch time of the same kernels from the PMC passes over an ADM forward
             # at B=4 (tools/adm_fwd.py), bound to the loaded binary by its source digest like the c2 figures
             traffic = mfma_busy = frac_rocprof = None
             pmc_note = "no profiles/*_adm_pmc_conv16.json carries the loaded library's source digest"
-            hit = pmc_for_loaded_binary(lib_digest, "_adm_pmc_conv16.json") if lib_digest else None
-            if hit is not None and B == 4:
+            hit = None
+            if lib_digest:          # the PMC passes are taken at B = 4 (c3 / c4) and at B = 8 (c5): pick this batch's file
+                hit = pmc_for_loaded_binary(lib_digest, f"_adm_pmc_conv16_b{B}.json") or \
+                    (pmc_for_loaded_binary(lib_digest, "_adm_pmc_conv16.json") if B == 4 else None)
+            if hit is not None:
                 fname, pj = hit
                 traffic, mfma_busy = pj.get("hbm_bytes_per_launch"), pj.get("mfma_busy_frac_weighted")
                 if pj.get("rocprof_avg_launch_us"):
                     frac_rocprof = round(r["flops"] / r["launches"] / (pj["rocprof_avg_launch_us"] * 1e-6) / 1e12
                                          / PEAK_F16_TFLOPS, 4)
-                pmc_note = f"profiles/{fname}: PMC passes over 2 ADM forwards at B=4 ({pj.get('kernel')}), same source digest"
-            elif hit is not None:
-                pmc_note = f"profiles/{hit[0]} was collected at B=4; this workload runs B={B}"
+                pmc_note = f"profiles/{fname}: PMC passes over 2 ADM forwards at B={B} ({pj.get('kernel')}), same source digest"
             res["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                                "mfma_busy_pmc": mfma_busy, "frac_rocprof": frac_rocprof, "traffic_note": pmc_note,
+                               "traffic_algorithmic": round(sum(alg) / max(1, len(alg)), 1),
+                               "mfma_work_tflops": round(achieved, 1),
                                "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                                "avg_flops_per_launch": r["flops"] / r["launches"],
                                "share_of_conv_time": round(r["ms"] / total_ms, 4),
@@ -429,9 +449,8 @@ def main():
         line.update(dist_info)
         if rank == 0:
             print(json.dumps(line), flush=True)
-        if world > 1:
-            ddist.barrier()
-            torch.distributed.destroy_process_group()
+        ddist.barrier()
+        ddist.shutdown()
         return
     model = Model(cfg, device=dev)
     sd = model.random_state_dict(seed=1234)          # identical replica on every rank, no broadcast
@@ -536,8 +555,17 @@ def main():
                 "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                 "avg_flops_per_launch": r["flops"] / r["launches"],
                 "share_of_conv_time": round(r["ms"] / total_ms, 4),
+                # MFMA work actually issued by the dominant kernel: 3 fp16 products per algorithmic product in the split
+                # form (compare THIS with the 2500 TFLOP/s dense fp16 peak; `achieved` with `peak`)
+                "mfma_work_tflops": round(achieved * (3 if name.startswith("conv3x3_halo_s16") else 1), 1),
                 "whole_loop_tflops": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world, 2),
+                # the loop holds split-fp16, fp32-MFMA and vector kernels, so its algorithmic rate is quoted against both
+                # fixed peaks by name: the split bound 2500 / 3 and the fp32 MFMA peak 157.3 of rounds 1-2
                 "whole_loop_frac": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world / peak, 4),
+                "whole_loop_frac_of_split16_bound_833": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world
+                                                              / PEAK_SPLIT16_TFLOPS, 4),
+                "whole_loop_frac_of_f32_mfma_peak_157": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world
+                                                              / PEAK_F32_TFLOPS, 4),
             }
         except Exception as e:    # noqa: BLE001
             ops.set_kernel_timer(None)
@@ -615,9 +643,8 @@ def main():
             except Exception as e:    # noqa: BLE001
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
-        ddist.barrier()
-        torch.distributed.destroy_process_group()
+    ddist.barrier()          # (no-ops without a process group; a launcher-started world of one runs them on RCCL)
+    ddist.shutdown()
 
 
 if __name__ == "__main__":

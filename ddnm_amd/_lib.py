@@ -30,6 +30,7 @@ class ConvDesc(Structure):
         ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
         ("SC0", c_int32), ("SC1", c_int32),
         ("acc_scale", c_float), ("reserved0", c_int32),
+        ("amax_in", c_void_p),
     ]
 
 
@@ -100,6 +101,10 @@ PROTOTYPES = {
     "ddnm_gn_finalize_tiles_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                              c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
                                              c_void_p, c_void_p]),
+    "ddnm_gn_finalize_tiles_amax_f32": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                                  c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int32,
+                                                  c_void_p, c_void_p, c_void_p]),
+    "ddnm_amax_bound_f32": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
     "ddnm_conv3x3_f16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv3x3_f16_supported": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_f16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
@@ -202,7 +207,7 @@ class DDNMHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def lib():

@@ -203,22 +203,46 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 // fp32 x4 -> hi | lo fp16 halves of a split row: hi at dst, lo 32 halfs behind it (split-fp16 kernels: conv_igemm_f16.hip <.., SPLIT>, conv_gather_s16.hip)
-#ifndef DDNM_S16_ASCALE
-// Power-of-two pre-scale of the activation operand (undone by acc_scale): 1.  The MFMA honours fp16 subnormals, so the
-// absolute error of hi + lo is <= 2^-25 for |v| < 0.25 and <= 2^-22 |v| above: tensors whose typical magnitude is >= ~0.1
-// (every GroupNorm'd / swish'd activation and the residual stream of the network) are carried to fp32 grade, a tensor that
-// is uniformly ~0.02 keeps ~1e-6 and one that is uniformly ~2e-4 keeps ~1e-4.  A larger pre-scale would move that floor
-// down but trade away overflow margin (fp16 overflows at 65504 / scale): with 16 the randomly initialised 256^2 UNet of
-// bench.py, whose residual stream reaches several thousand, overflowed in its raw-operand launches (Downsample, proj_out).
-#define DDNM_S16_ASCALE 1.0f
-#endif
-__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {
-    v = v * DDNM_S16_ASCALE;
+// `s` = the launch's power-of-two operand scale (s16_operand_scale below; 1 for GroupNorm'd operands).  The MFMA honours
+// fp16 subnormals, so the absolute error of hi + lo is <= 2^-25 for |s v| < 0.25 and <= 2^-22 |v| above.
+#define DDNM_S16_ASCALE 1.0f       // compile-time pre-scale of ABI 4, kept at 1: the scale is per launch and image now
+__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v, const float s) {
+    v = v * s;
     const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
     const half4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
                      (_Float16)(v.w - (float)h.w)};
     *reinterpret_cast<half4*>(dst) = h;
     *reinterpret_cast<half4*>(dst + 32) = l;
+}
+__device__ __forceinline__ void split_store(_Float16* dst, f32x4 v) {      // unscaled (GroupNorm'd operand, no raw shortcut)
+    const half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const half4 l = {(_Float16)(v.x - (float)h.x), (_Float16)(v.y - (float)h.y), (_Float16)(v.z - (float)h.z),
+                     (_Float16)(v.w - (float)h.w)};
+    *reinterpret_cast<half4*>(dst) = h;
+    *reinterpret_cast<half4*>(dst + 32) = l;
+}
+
+// Operand-range guard of the split forms (include/ddnm_hip.h::ddnm_conv_desc::amax_in): the DDNM_AMAX_N bound words of
+// image `img` are wave-uniform scalar loads (s_load: they count on lgkmcnt, not on the vmcnt the main loops count), their
+// maximum is taken on the bit patterns (non-negative floats order like unsigned integers), and the scale is the power of
+// two that brings the bound into [2^14, 2^15).  `down_only`: the raw operand shares its accumulator with a GroupNorm'd
+// one (fused shortcut), which is O(1): scale down for huge inputs, never up.  The exponent is clamped so that the scale,
+// its inverse and their product with acc_scale stay normal numbers; an all-zero (or non-finite) operand needs no care.
+__device__ __forceinline__ void s16_operand_scale(const float* __restrict__ amax_in, int img, bool down_only,
+                                                  float& scale, float& inv_scale) {
+    scale = inv_scale = 1.f;
+    if (amax_in == nullptr) return;
+    const unsigned* __restrict__ w = reinterpret_cast<const unsigned*>(amax_in) + (size_t)img * DDNM_AMAX_N;
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < DDNM_AMAX_N; ++i) m = w[i] > m ? w[i] : m;
+    m = __builtin_amdgcn_readfirstlane(m);
+    int e = (int)((m >> 23) & 0xffu);                 // biased exponent of the bound (sign bit is 0)
+    e = e < 47 ? 47 : (e > 207 ? 207 : e);            // 2^-80 ... 2^80
+    int k = 14 - (e - 127);
+    if (down_only && k > 0) k = 0;
+    scale = __uint_as_float((unsigned)(127 + k) << 23);
+    inv_scale = __uint_as_float((unsigned)(127 - k) << 23);
 }
 
 __device__ __forceinline__ f32x4 gn_act(f32x4 v, const f32x4 gsc, const f32x4 gsh, int silu) {

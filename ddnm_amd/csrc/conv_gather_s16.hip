@@ -38,6 +38,10 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
     const int slice = blockIdx.y;
     const TileMap tm = make_tilemap<BM>(p, m_tile);
     const int img = tm.img;
+    // operand-range guard: per-launch, per-image power-of-two scale of a RAW operand (Downsample, nin_shortcut, proj_out);
+    // GroupNorm'd operands (qkv) carry no bound and run with 1 (scalar loads: no effect on the vmcnt bookkeeping below)
+    float ascale, inv_ascale;
+    s16_operand_scale(d.gn_scale == nullptr ? d.amax_in : nullptr, img, false, ascale, inv_ascale);
 
     const int c4 = tid & 7, row0 = tid >> 3;   // A: float4 column (4 channels) of rows row0 + 32 i
     int iy0[AR], ix0[AR];
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
         for (int i = 0; i < AR; ++i) {
             f32x4 v = a_st[i];
             if (has_gn && (a_valid & (1u << i))) v = gn_act(v, gsc, gsh, d.gn_silu);
-            split_store(&As[(row0 + 32 * i) * GS_LDH + c4 * 4], v);       // hi at channel c4*4, lo 32 halfs behind it
+            split_store(&As[(row0 + 32 * i) * GS_LDH + c4 * 4], v, ascale);   // hi at channel c4*4, lo 32 halfs behind it
         }
     };
 
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_gather_s16_kernel(const ConvArgs p) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail requests
     }
     __syncthreads();               // the statistics epilogue reuses As
-    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, reinterpret_cast<float*>(As), d.acc_scale);
+    conv_epilogue<WM, WN, MT, NT>(p, tm, n_tile, m_tile, slice, acc, reinterpret_cast<float*>(As), d.acc_scale * inv_ascale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -260,6 +264,10 @@ extern "C" int ddnm_conv_gather_s16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (!(d->acc_scale > 0.f)) return DDNM_E_BADARG;
+    {   // a raw operand needs the operand bound (fp16 range); DDNM_S16_UNGUARDED=1 lifts that for probes
+        static const bool unguarded = [] { const char* e = getenv("DDNM_S16_UNGUARDED"); return e && e[0] == '1'; }();
+        if (!d->gn_scale && !d->amax_in && !unguarded) return DDNM_E_BADARG;
+    }
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     PlanGS pl;

@@ -50,9 +50,15 @@ constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 // i.e. the same 128 + 16 bytes as a 64-channel fp16 row, the weights arrive packed the same way ([hi 32 | lo 32]
 // per (row, tap, chunk), pre-scaled by a power of two so that `lo` stays a normal fp16 number) and
 // ddnm_conv_desc::acc_scale undoes the scaling in the epilogue.
-template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false>
+//
+// ASCALE (split form only) = the launch carries an operand bound (ddnm_conv_desc::amax_in): raw operands -- the main
+// operand of a launch without GroupNorm (Upsample convolution) and the fused shortcut's input -- are multiplied by a
+// per-launch, per-image power of two while they are split, and the accumulator by its inverse (conv_common.h::
+// s16_operand_scale).  Launches whose operands are all GroupNorm'd run the ASCALE = false instance (no multiply).
+template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false, bool ASCALE = false>
 __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
     static_assert(!(SPLIT && SRC16), "the split form reads fp32 activations");
+    static_assert(SPLIT || !ASCALE, "operand scaling belongs to the split form");
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int MAXH = BM == 512 ? 612 : (BM == 256 ? 340 : (BM == 128 ? 204 : 136));
@@ -86,6 +92,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const int img = tm.img;
     const int TH = BM >> p.TW_log2, HWd = p.TW + 2;
     const int NP = (TH + 2) * HWd;
+    // operand-range guard (scalar loads: nothing here touches the vmcnt bookkeeping of the main loop)
+    float ascale = 1.f, epi_scale = SPLIT ? d.acc_scale : 1.f;
+    if constexpr (ASCALE) {
+        float inv;
+        s16_operand_scale(d.amax_in, img, /*down_only=*/d.gn_scale != nullptr, ascale, inv);
+        epi_scale = d.acc_scale * inv;
+    }
 
     // ---- halo loader mapping: thread -> (16-byte column hc of HCOLS, halo rows prow + HROWS_PER_PASS*i)
     const int hc = tid % HCOLS, prow = tid / HCOLS;
@@ -144,22 +157,29 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     const __amdgpu_buffer_rsrc_t r_s1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(reinterpret_cast<const void*>(d.C1 > 0 ? d.src1 : d.src0)), 0,
         (unsigned)d.B * p.Hs * p.Ws * (d.C1 > 0 ? d.C1 : d.C0) * ESZ, 0x00020000);
-    auto prefetch_halo_part = [&](int chunk, int i0, int i1) {
+    // `live` = false turns every request of the call into an out-of-range one (returns zero, no memory traffic): the last
+    // chunk of a slice still issues the SAME number of requests per tap as every other chunk, so the `vmcnt` immediates of
+    // the main loop are compile-time constants of a branch-free request stream (tests/test_isa_waits.py replays the
+    // stream from the ISA and checks every immediate against it).  The GroupNorm vectors are fetched unconditionally
+    // (from the weights when the launch has no GroupNorm, like the gather form).
+    const float* const gn_sc_base = has_gn ? d.gn_scale + (size_t)img * p.Cin + hc * 4 : reinterpret_cast<const float*>(d.weight);
+    const float* const gn_sh_base = has_gn ? d.gn_shift + (size_t)img * p.Cin + hc * 4 : reinterpret_cast<const float*>(d.weight);
+    auto prefetch_halo_part = [&](int chunk, int i0, int i1, bool live = true) {
         const int cb = chunk * KCH;
         const bool first = cb < d.C0;
         const unsigned cs = first ? d.C0 : d.C1, coff = first ? cb : cb - d.C0;
+        const __amdgpu_buffer_rsrc_t r_s = first ? r_s0 : r_s1;              // wave-uniform: a scalar select, no branch
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
             if (i < i0 || i >= i1) continue;
-            const unsigned vo = hoff[i] >= 0 ? ((unsigned)hoff[i] * cs + hc * HVEC) * ESZ : HOOB;
-            const u32x4 v = first ? __builtin_amdgcn_raw_buffer_load_b128(r_s0, vo, coff * ESZ, 0)
-                                  : __builtin_amdgcn_raw_buffer_load_b128(r_s1, vo, coff * ESZ, 0);
+            const unsigned vo = (hoff[i] >= 0 && live) ? ((unsigned)hoff[i] * cs + hc * HVEC) * ESZ : HOOB;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_s, vo, coff * ESZ, 0);
             h_st[i] = uint4{v.x, v.y, v.z, v.w};
         }
         if constexpr (!SRC16) {
-            if (has_gn && i0 == 0) {
-                gsc = *reinterpret_cast<const f32x4*>(d.gn_scale + (size_t)img * p.Cin + cb + hc * 4);
-                gsh = *reinterpret_cast<const f32x4*>(d.gn_shift + (size_t)img * p.Cin + cb + hc * 4);
+            if (i0 == 0) {
+                gsc = *reinterpret_cast<const f32x4*>(gn_sc_base + (has_gn ? cb : 0));
+                gsh = *reinterpret_cast<const f32x4*>(gn_sh_base + (has_gn ? cb : 0));
             }
         }
     };
@@ -178,7 +198,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #ifndef DDNM_PROBE_NO_GN              // timing probe (wrong results): no GroupNorm affine / swish in the loader
                     if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
 #endif
-                    if constexpr (SPLIT) {
+                    if constexpr (SPLIT && ASCALE) {
+                        split_store(dst, v, ascale);
+                    } else if constexpr (SPLIT) {
                         split_store(dst, v);
                     } else {
                         half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
@@ -311,11 +333,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                 // this wave's halo ds_writes of taps 3 / 6 are in LDS before anybody can be past the barrier)
                 // the halo loads of taps 0 / 3 (requested behind W(step+2) of those taps, i.e. younger than the tile awaited
                 // here at the two following taps) stay in flight as well: they come from HBM and are not needed before
-                // taps 3 / 6, where the compiler waits for their registers
-                if ((tap == 1 || tap == 2) && more) {
-                    if (has_gn) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HSPLIT + 2) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HSPLIT) : "memory");
-                } else if ((tap == 4 || tap == 5) && more) {
+                // taps 3 / 6, where the compiler waits for their registers.  Every immediate is a compile-time constant of
+                // a branch-free request stream; tests/test_isa_waits.py replays the stream from the ISA.
+                constexpr int GNV = SRC16 ? 0 : 2;         // GroupNorm vectors requested with halo part 0
+                if (tap == 1 || tap == 2) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HSPLIT + GNV) : "memory");
+                } else if (tap == 4 || tap == 5) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR + HR - HSPLIT) : "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
@@ -325,11 +348,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
                 asm volatile("" ::: "memory");
 #endif
                 issue_step(step + 2, cur >= 1 ? cur - 1 : NWB - 1);     // (step + 2) % 3: the buffer W(step - 1) just left
-                if (more) {
-                    if (tap == 0) prefetch_halo_part(chunk + 1, 0, HSPLIT);
-                    if (tap == 3) { stage_halo_part(hb ^ 1, 0, HSPLIT); prefetch_halo_part(chunk + 1, HSPLIT, HR); }
-                    if (tap == 6) stage_halo_part(hb ^ 1, HSPLIT, HR);
+                // pin the issue order the counted waits assume: this tap's DMA requests first, then its halo requests
+                // (the scheduler may not move anything across; the compiler barrier keeps IR passes from sinking the loads)
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                // the next chunk's halo: requested at taps 0 / 3 (on the last chunk as out-of-range requests that return
+                // zero: the request stream stays uniform), GroupNorm'd / split / written to the other buffer at taps 3 / 6
+                const int nchunk = more ? chunk + 1 : chunk;
+                if (tap == 0) prefetch_halo_part(nchunk, 0, HSPLIT, more);
+                if (tap == 3) {
+                    if (more) stage_halo_part(hb ^ 1, 0, HSPLIT);
+                    prefetch_halo_part(nchunk, HSPLIT, HR, more);
                 }
+                if (tap == 6 && more) stage_halo_part(hb ^ 1, HSPLIT, HR);
 #ifndef DDNM_PROBE16_NO_SCHED_BARRIER
                 // keep the requests issued above in front of this tap's MFMAs: left alone, the scheduler sinks
                 // them behind the MFMAs (VGPR pressure) and their latency lands on the barrier of every tap
@@ -393,7 +424,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #pragma unroll
             for (int i = 0; i < SR; ++i) {
                 const f32x4 v = s_st[i];
-                if constexpr (SPLIT) {
+                if constexpr (SPLIT && ASCALE) {
+                    split_store(&Hs[sdst[i]], v, ascale);
+                } else if constexpr (SPLIT) {
                     split_store(&Hs[sdst[i]], v);
                 } else {
                     half4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
             mfma_tap(4, 0);
         }
     }
-    conv_epilogue<WM, WN, MT, NT, (MT * NT <= 4)>(p, tm, n_tile, m_tile, slice, acc, stat_lds, SPLIT ? d.acc_scale : 1.f);
+    conv_epilogue<WM, WN, MT, NT, (MT * NT <= 4)>(p, tm, n_tile, m_tile, slice, acc, stat_lds, epi_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,10 +495,18 @@ extern "C" int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d) {
     return pl.ksplit > 1 ? splitk_stats_tiles(d) : d->Ho * d->Wo / pl.BM;
 }
 
+// DDNM_S16_UNGUARDED=1 (probes / A-B timing only): accept raw-operand split launches without an operand bound
+static bool s16_unguarded_ok() {
+    static const bool ok = [] { const char* e = getenv("DDNM_S16_UNGUARDED"); return e && e[0] == '1'; }();
+    return ok;
+}
+
 static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     const int kch = split ? KC16 / 2 : KC16;
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
     if (split && (d->src_f16 || !(d->acc_scale > 0.f))) return DDNM_E_BADARG;
+    // raw operands (no GroupNorm in front of the main operand, or a fused shortcut) need the operand bound: fp16 range
+    if (split && !d->amax_in && (!d->gn_scale || d->skip0) && !s16_unguarded_ok()) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
@@ -507,7 +548,8 @@ static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
 #else
-    if (split) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>), grid, dim3(512), 0, s, p); }
+    if (split && d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, true>), grid, dim3(512), 0, s, p); }
+    else if (split) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>), grid, dim3(512), 0, s, p); }
     else if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), grid, dim3(512), 0, s, p); }
 #endif

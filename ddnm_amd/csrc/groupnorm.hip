@@ -150,9 +150,12 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
                                                                 float eps, float* __restrict__ scale,
                                                                 float* __restrict__ shift,
                                                                 const float* __restrict__ film, int film_stride,
-                                                                float* __restrict__ mean_rstd) {
+                                                                float* __restrict__ mean_rstd,
+                                                                float* __restrict__ amax_out) {
     __shared__ double red[4][2];
     __shared__ float mean_s, rstd_s;
+    __shared__ float qmax_s[4];
+    float qmax = 0.f;      // largest per-(tile, channel) sum of squares of the group: sqrt() bounds max |x| (amax_out)
     const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const int C = C0 + C1, cpg = C / groups;
     const int c_lo = g * cpg;
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         const float2 v = *reinterpret_cast<const float2*>(part0 + (((size_t)b * tpi0 + t) * C0 + c) * 2);
         a += (double)v.x;
         q += (double)v.y;
+        qmax = fmaxf(qmax, v.y);
     }
     const int c1_lo = c_lo + n0 - C0;
     for (int it = tid; it < items1; it += 256) {
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         const float2 v = *reinterpret_cast<const float2*>(part1 + (((size_t)b * tpi1 + t) * C1 + c) * 2);
         a += (double)v.x;
         q += (double)v.y;
+        qmax = fmaxf(qmax, v.y);
     }
     // fixed-shape reduction (deterministic): xor-butterfly inside each wave, then the four wave sums in order --
     // one barrier instead of the eight of an LDS tree (this kernel is pure latency: 101 launches per ADM forward)
@@ -191,8 +196,18 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         a += __shfl_xor(a, o);
         q += __shfl_xor(q, o);
     }
+    if (amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qmax = fmaxf(qmax, __shfl_xor(qmax, o));
+        if ((tid & 63) == 0) qmax_s[tid >> 6] = qmax;
+    }
     if ((tid & 63) == 0) { red[tid >> 6][0] = a; red[tid >> 6][1] = q; }
     __syncthreads();
+    if (amax_out && tid == 64) {
+        // a NaN / inf partial propagates as inf: the consumer's result is non-finite either way
+        const float m = fmaxf(fmaxf(qmax_s[0], qmax_s[1]), fmaxf(qmax_s[2], qmax_s[3]));
+        amax_out[(size_t)b * groups + g] = sqrtf(m) * 1.0009765625f;        // (1 + 2^-10): rounding of the fp32 partial sums
+    }
     if (tid == 0) {
         red[0][0] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         red[0][1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
@@ -224,16 +239,69 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
     }
 }
 
-extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int32_t C0, const float* part1,
-                                          int32_t tpi1, int32_t C1, const float* gamma, const float* beta, int32_t B,
-                                          int32_t HW, int32_t groups, float eps, float* scale, float* shift,
-                                          const float* film, int32_t film_stride, float* mean_rstd, void* stream) {
+extern "C" int ddnm_gn_finalize_tiles_amax_f32(const float* part0, int32_t tpi0, int32_t C0, const float* part1,
+                                               int32_t tpi1, int32_t C1, const float* gamma, const float* beta, int32_t B,
+                                               int32_t HW, int32_t groups, float eps, float* scale, float* shift,
+                                               const float* film, int32_t film_stride, float* mean_rstd, float* amax_out,
+                                               void* stream) {
     if (!part0 || !gamma || !beta || !scale || !shift || B <= 0 || tpi0 <= 0 || C0 <= 0) return DDNM_E_BADARG;
     if (C1 > 0 && (!part1 || tpi1 <= 0)) return DDNM_E_BADARG;
     const int C = C0 + C1;
     if (groups <= 0 || C % groups || C / groups > 256) return DDNM_E_SHAPE;
+    if (amax_out && groups != DDNM_AMAX_N) return DDNM_E_SHAPE;
     DDNM_LAUNCH(gn_finalize_tiles_kernel, dim3(B, groups), dim3(256), 0, (hipStream_t)stream, part0, tpi0, C0, part1, tpi1,
-                C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride, mean_rstd);
+                C1, gamma, beta, HW, groups, eps, scale, shift, film, film_stride, mean_rstd, amax_out);
+    return 0;
+}
+
+extern "C" int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tpi0, int32_t C0, const float* part1,
+                                          int32_t tpi1, int32_t C1, const float* gamma, const float* beta, int32_t B,
+                                          int32_t HW, int32_t groups, float eps, float* scale, float* shift,
+                                          const float* film, int32_t film_stride, float* mean_rstd, void* stream) {
+    return ddnm_gn_finalize_tiles_amax_f32(part0, tpi0, C0, part1, tpi1, C1, gamma, beta, B, HW, groups, eps, scale, shift,
+                                           film, film_stride, mean_rstd, nullptr, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Operand bound of the split-fp16 convolutions (ddnm_conv_desc::amax_in) for raw operands that no GroupNorm reads first:
+// grid (B, DDNM_AMAX_N), block (b, i) scans the i-th 1/32 slice of image b's data of up to two sources with 16-byte loads.
+// kind 0: the tensor itself (max |x|); kind 1: its GroupNorm partials, pairs (sum, sum of squares): sqrt(max sumsq) >= max |x|.
+// No atomics: 32 words per image, the consumer takes their maximum with scalar instructions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_bound_kernel(const float* __restrict__ src0, int64_t n40, int kind0,
+                                                         const float* __restrict__ src1, int64_t n41, int kind1,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, i = blockIdx.y, tid = threadIdx.x;
+    float m = 0.f;
+    auto scan = [&](const float* __restrict__ src, int64_t n4, int kind) {
+        const int64_t chunk = (n4 + DDNM_AMAX_N - 1) / DDNM_AMAX_N;
+        const int64_t lo = (int64_t)i * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+        const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(src) + (int64_t)b * n4;
+        float q = 0.f;
+        for (int64_t j = lo + tid; j < hi; j += 256) {
+            const f32x4 v = p[j];
+            if (kind) q = fmaxf(q, fmaxf(v.y, v.w));
+            else q = fmaxf(q, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+        m = fmaxf(m, kind ? sqrtf(q) * 1.0009765625f : q);
+    };
+    scan(src0, n40, kind0);
+    if (src1) scan(src1, n41, kind1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) out[(size_t)b * DDNM_AMAX_N + i] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+extern "C" int ddnm_amax_bound_f32(const float* src0, int64_t per_image0, int32_t kind0, const float* src1,
+                                   int64_t per_image1, int32_t kind1, float* out, int32_t B, void* stream) {
+    if (!src0 || !out || B <= 0 || per_image0 <= 0 || (per_image0 & 3)) return DDNM_E_BADARG;
+    if (src1 && (per_image1 <= 0 || (per_image1 & 3))) return DDNM_E_BADARG;
+    if ((kind0 | kind1) & ~1) return DDNM_E_BADARG;
+    DDNM_LAUNCH(amax_bound_kernel, dim3(B, DDNM_AMAX_N), dim3(256), 0, (hipStream_t)stream, src0, per_image0 / 4, kind0, src1,
+                src1 ? per_image1 / 4 : 0, kind1, out);
     return 0;
 }
 

@@ -16,15 +16,32 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment (backend "nccl" == RCCL on ROCm)."""
+# A process group of ONE rank still runs its collectives when the process was started by a distributed launcher (RANK and
+# WORLD_SIZE in the environment: `torchrun --nproc-per-node 1`) or when a caller passes force=True: the RCCL code path of
+# an 8-GPU job is then exactly the one a 1-GPU box can execute and test (tests/test_gpu_rccl.py).
+_COLLECTIVES_AT_WORLD_1 = False
+
+
+def _active(force=False):
+    return dist.is_initialized() and (dist.get_world_size() > 1 or force or _COLLECTIVES_AT_WORLD_1)
+
+
+def init(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment (backend "nccl" == RCCL on ROCm).  A world of one is
+    initialised too when a launcher started the process (RANK / WORLD_SIZE exported) or `force` is set."""
+    global _COLLECTIVES_AT_WORLD_1
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world == 1 and (force or launched) and os.environ.get("DDNM_DIST_WORLD1", "1") != "0":
+        _COLLECTIVES_AT_WORLD_1 = True
+    if (world > 1 or _COLLECTIVES_AT_WORLD_1) and not dist.is_initialized():
         if backend is None:
             # "nccl" is RCCL on ROCm; DDNM_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box)
             backend = os.environ.get("DDNM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -51,9 +68,9 @@ def shard_batch(rank, world, *tensors):
     return out
 
 
-def gather_images(x_local, n_total=None):
+def gather_images(x_local, n_total=None, force=False):
     """The path's single collective: all ranks receive the full restored batch, in image order."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(force):
         return x_local
     world = dist.get_world_size()
     n_total = x_local.shape[0] * world if n_total is None else n_total
@@ -74,12 +91,12 @@ def gather_images(x_local, n_total=None):
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
 
 
-def reduce_scalar(value, device, op="sum"):
+def reduce_scalar(value, device, op="sum", force=False):
     """Scalar sum / max / min over ranks (gloo reduces host tensors, RCCL device tensors)."""
-    if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "gloo":
+    if _active(force) and dist.get_backend() == "gloo":
         device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active(force):
         dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
     return t.item()
 
@@ -103,17 +120,17 @@ def backend_name():
     return dist.get_backend() if dist.is_initialized() else "none"
 
 
-def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def barrier(force=False):
+    if _active(force):
         if dist.get_backend() == "nccl":          # pin the RCCL barrier to this rank's GPU
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
             dist.barrier()
 
 
-def broadcast_flag(flag):
+def broadcast_flag(flag, force=False):
     """Rank 0's boolean, on every rank (a collective: also orders rank 0's side effects before the others go on)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active(force):
         return bool(flag)
     dev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", torch.cuda.current_device())
     t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
@@ -122,5 +139,7 @@ def broadcast_flag(flag):
 
 
 def shutdown():
+    global _COLLECTIVES_AT_WORLD_1
     if dist.is_initialized():
         dist.destroy_process_group()
+    _COLLECTIVES_AT_WORLD_1 = False

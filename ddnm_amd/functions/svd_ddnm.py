@@ -26,6 +26,8 @@ device generator like the reference's `torch.randn_like`.
 benchmark and the parity tests pass False and keep the result in HBM.  `record(k, name, tensor)`
 is an optional probe called with the device tensors `x0_t` / `xt_next` after iteration k.
 """
+import contextlib
+
 import torch
 
 from .. import ops
@@ -88,6 +90,17 @@ def _guided_eps(et, grad, coef):
     return out
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device, priority):
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), priority)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return st
+
+
 class _GuidanceAhead:
     """Classifier guidance on its own HIP stream, one reverse step ahead of the UNet.
 
@@ -109,7 +122,9 @@ class _GuidanceAhead:
             self.main = torch.cuda.current_stream()
             # high priority: the guidance pass is a long chain of small dependent launches (latency-bound), the UNet a
             # sequence of chip-filling ones -- the chain must not queue behind them, the big kernels soak up the rest
-            self.side = torch.cuda.Stream(device=x.device, priority=int(os.environ.get("DDNM_CLS_PRIO", "-1")))
+            # ONE side stream per (device, priority) for the life of the process: the convolution / GroupNorm workspaces
+            # are keyed by the stream handle, a fresh stream per call would grow them by one set per batch
+            self.side = _side_stream(x.device, int(os.environ.get("DDNM_CLS_PRIO", "-1")))
             self.side.wait_stream(self.main)             # x (and the operator's set-up) are complete
             self._launch()
 
@@ -183,9 +198,10 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     have_x0 = False
     guide = None
-    with torch.no_grad():
+    with torch.no_grad(), contextlib.ExitStack() as _stack:
         if cls_fn is not None:
             guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
+            _stack.callback(guide.close)         # also when the loop raises: the main stream re-joins the side stream
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
             if j < 0:
@@ -218,13 +234,11 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
             if record is not None:
                 record(k, "x0_t", x0_t)
                 record(k, "xt_next", xt)
-        if guide is not None:
-            guide.close()
     return _finish(xt, x0_t, return_cpu)
 
 
 def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, classes=None, config=None, noise=None,
-                        return_cpu=True):
+                        return_cpu=True, record=None):
     """DDNM+ for noisy measurements: drop-in for `functions/svd_ddnm.py::ddnm_plus_diffusion` (:80-164).
 
       x0|t  = (x_t - eps*sqrt(1-abar_t)) / sqrt(abar_t)                                  (Eq. 12)
@@ -249,9 +263,10 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     have_x0 = False
     guide = None
-    with torch.no_grad():
+    with torch.no_grad(), contextlib.ExitStack() as _stack:
         if cls_fn is not None:
             guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
+            _stack.callback(guide.close)         # also when the loop raises: the main stream re-joins the side stream
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
             if j < 0:
@@ -282,6 +297,7 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                 assert have_x0
                 ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
-        if guide is not None:
-            guide.close()
+            if record is not None:
+                record(k, "x0_t", x0_t)
+                record(k, "xt_next", xt)
     return _finish(xt, x0_t, return_cpu)

@@ -112,11 +112,19 @@ def _gather(vec, idx, n_out, scale=None):
 
 
 def _site_matmul(vec, M, sites, n, sb, ss, sj, trans):
-    if n > 16:      # ddnm_site_matmul_f32 keeps one n x n site matrix in registers (n <= 16: ratio <= 4, colour = 3)
-        raise NotImplementedError(f"matrix-free V / Vt / At / A_pinv_eta with {n} entries per site (sr_averagepooling "
-                                  "with deg_scale > 4): only the direct A / A_pinv forms the sampler uses are built")
     v = _flat(vec)
     out = torch.empty_like(v)
+    if n > 16:
+        # ddnm_site_matmul_f32 keeps one n x n site matrix in registers (n <= 16: ratio <= 4, colour = 3).  Larger sites
+        # (sr_averagepooling with deg_scale 8 / 16 / 32, evaluation.sh:18: n = ratio^2 entries per patch) lie contiguously
+        # in the site-major layout, so all sites of all images are the rows of ONE matrix and V_small / Vt_small act as a
+        # single MFMA GEMM: out[B*sites][n] = in[B*sites][n] . Mop^T  (svd_operators.py:490-517)
+        if sj != 1 or ss != n or sb != sites * n:
+            raise NotImplementedError(f"site matrix with {n} entries per site needs the contiguous site-major layout")
+        rows = v.shape[0] * sites
+        # Mop = M (trans 0): out = in . M^T -> B operand stored [N = i][K = j] = M itself; Mop = M^T: stored [K = j][N = i]
+        ops.bgemm(v, M, out, rows, n, n, lda=n, ldb=n, ldc=n, transb=not trans)
+        return out
     check(_lib.lib().ddnm_site_matmul_f32(_p(v), _p(M), _p(out), v.shape[0], sites, n, sb, ss, sj, int(trans),
                                           ops._stream()), "ddnm_site_matmul_f32")
     return out

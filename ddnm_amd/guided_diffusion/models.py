@@ -304,12 +304,20 @@ class Model:
         self._ws = ent[0]
         return self._ws
 
-    def _gn(self, x0, x1, name):
-        return ops.group_norm_affine(x0, x1, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws)
+    def _gn(self, x0, x1, name, want_amax=False):
+        return ops.group_norm_affine(x0, x1, self.w[name + ".weight"], self.w[name + ".bias"], GN_EPS, self._ws,
+                                     want_amax=want_amax)
 
     def _resblock(self, rb, x0, x1, tproj):
         w, n = self.w, rb.name
-        gn1 = self._gn(x0, x1, n + ".norm1")
+        # a block with a 1x1 shortcut reads its input RAW as well: the finalize launch of norm1 also emits the operand
+        # bound of (x0, x1) for the split-fp16 kernels' range guard (ops.conv2d(raw_amax=...)), at no extra launch
+        x_amax = None
+        if rb.cin != rb.cout and self.split16:
+            *gn1, x_amax = self._gn(x0, x1, n + ".norm1", want_amax=True)
+            gn1 = tuple(gn1)
+        else:
+            gn1 = self._gn(x0, x1, n + ".norm1")
         h = ops.conv2d(x0, w[n + ".conv1.weight"], rb.cout, 3, src1=x1, gn=gn1, gn_silu=True,
                        badd=tproj[:, rb.temb_off:], badd_stride=self.temb_total, emit_stats=True,
                        weight_s16=w.get(n + ".conv1.s16"))
@@ -324,9 +332,9 @@ class Model:
                 return ops.conv2d(h, w[n + ".conv2.weight"], rb.cout, 3, gn=gn2, gn_silu=True,
                                   bias=w[n + ".conv2_plus_shortcut.bias"], skip=(x0, x1),
                                   skip_weight=w[n + ".nin_shortcut.fused"], emit_stats=True,
-                                  weight_s16=w.get(n + ".conv2.s16"))
+                                  weight_s16=w.get(n + ".conv2.s16"), raw_amax=x_amax)
             xs = ops.conv2d(x0, w[n + ".nin_shortcut.weight"], rb.cout, 1, src1=x1, bias=w[n + ".nin_shortcut.bias"],
-                            weight_s16=w.get(n + ".nin_shortcut.s16"))
+                            weight_s16=w.get(n + ".nin_shortcut.s16"), raw_amax=x_amax)
         else:
             assert x1 is None
             xs = x0

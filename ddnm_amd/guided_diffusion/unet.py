@@ -323,9 +323,10 @@ class UNetModel:
 
     def _gn(self, x0, x1, name, film=None):
         if x1 is None and isinstance(x0, ops.Act) and x0.gn is not None and x0.gn[2] == name \
-                and os.environ.get("DDNM_NO_FUSED_FIN") != "1":
-            # already finalized by the launch that produced x0 (its split-K reduction pass): no launch here
-            sc, sh, _ = x0.gn
+                and x0.gn[3].generation == x0.gn[4] and os.environ.get("DDNM_NO_FUSED_FIN") != "1":
+            # already finalized by the launch that produced x0 (its split-K reduction pass), and no other GroupNorm has
+            # written the shared scale / shift buffers since (generation counter): no launch here
+            sc, sh = x0.gn[0], x0.gn[1]
             x0.gn = None
             return sc, sh
         f, fs = (None, 0) if film is None else (film, self.film_total)

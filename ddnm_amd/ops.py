@@ -90,10 +90,12 @@ _NO_FUSED_GN = _os.environ.get("DDNM_NO_FUSED_GN") == "1"      # A/B switch for 
 class Act:
     """An NHWC activation plus, when its producer could emit them, the GroupNorm partials of it
     (per-(M tile, channel) sum / sum of squares written by the convolution epilogue)."""
-    __slots__ = ("t", "stats", "tiles", "gn")
+    __slots__ = ("t", "stats", "tiles", "gn", "amax")
 
-    def __init__(self, t, stats=None, tiles=0, gn=None):
+    def __init__(self, t, stats=None, tiles=0, gn=None, amax=None):
         self.t, self.stats, self.tiles = t, stats, tiles
+        # [B][AMAX_N] fp32 upper bounds of |t| per image (operand-range guard of the split-fp16 kernels, see amax_bound)
+        self.amax = amax
         # (scale, shift, name): the affine of the consumer GroupNorm `name`, already finalized by the producing launch
         # (split-K reduction pass, ddnm_conv16_desc::fin_*); valid until the next finalize reuses the workspace
         self.gn = gn
@@ -196,13 +198,43 @@ def _f16_scratch(device, numel, slot=0):
     return buf
 
 
+AMAX_N = 32          # include/ddnm_hip.h::DDNM_AMAX_N
+_S16_CHECK = _os.environ.get("DDNM_S16_CHECK") == "1"      # debug: assert finiteness after every split-fp16 launch (syncs)
+
+
+def amax_bound(a0, a1=None):
+    """[B][AMAX_N] per-image upper bounds of |concat(a0, a1)| for the operand-range guard of the split-fp16 kernels
+    (ddnm_conv_desc::amax_in): from the producers' GroupNorm partials when the `Act`s carry them (a few KB ... 2 MB read),
+    otherwise from the tensors themselves.  One small launch, no host synchronisation."""
+    def src(a):
+        if a is None:
+            return None, 0, 0
+        if isinstance(a, Act) and a.stats is not None:
+            B = a.t.shape[0]
+            return a.stats, a.stats.numel() // B, 1
+        t = a.t if isinstance(a, Act) else a
+        return _f32c(t, "amax source"), t.numel() // t.shape[0], 0
+    t0 = a0.t if isinstance(a0, Act) else a0
+    B = t0.shape[0]
+    p0, n0, k0 = src(a0)
+    p1, n1, k1 = src(a1)
+    out = torch.empty(B * AMAX_N, dtype=torch.float32, device=t0.device)
+    check(_lib.lib().ddnm_amax_bound_f32(_p(p0), n0, k0, _p(p1), n1, k1, _p(out), B, _stream()), "ddnm_amax_bound_f32")
+    return out
+
+
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
-           emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None, weight_s16=None):
+           emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None, weight_s16=None,
+           raw_amax=None):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
     With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them).
     weight_s16 = (packed, scale, packed_skip or None) from pack_conv_weight_s16: 3x3 / stride-1 launches whose shape
-    qualifies then run the split-fp16 kernel (fp32-grade products on the fp16 matrix pipe) instead of the fp32 one."""
+    qualifies then run the split-fp16 kernel (fp32-grade products on the fp16 matrix pipe) instead of the fp32 one.
+    Operands such a launch reads RAW (no GroupNorm: the main operand when gn is None, the fused shortcut's input always)
+    are range-guarded: `raw_amax` = their [B][AMAX_N] bound (amax_bound / group_norm_affine(want_amax=True)); when it is
+    not supplied it is computed here from the producers' partials or the tensors."""
+    a_src0, a_src1 = src0, src1                 # (possibly `Act`s: their partials feed the operand bound)
     src0 = src0.t if isinstance(src0, Act) else src0
     src1 = src1.t if isinstance(src1, Act) else src1
     res = res.t if isinstance(res, Act) else res
@@ -243,14 +275,24 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
     # shape qualifies; everything else runs the exact-fp32 kernels
     f16, f16_1x1 = False, False
+    if skip is not None:        # the support queries below look at the shortcut's channel counts too
+        d.SC0 = (skip[0].t if isinstance(skip[0], Act) else skip[0]).shape[3]
+        d.SC1 = 0 if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1]).shape[3]
     s16 = (weight_s16 is not None and weight_f16 is None and ksize == 3 and stride == 1
-           and (skip is None or weight_s16[2] is not None) and L.ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1)
+           and (skip is None or (weight_s16[2] is not None and gn is not None and d.SC0 % 32 == 0 and d.SC1 % 32 == 0))
+           and L.ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1)
     # ... and the per-tap gather form of the same arithmetic for 1x1 / strided / 8x8-level launches (no fused shortcut)
     s16g = (not s16 and weight_s16 is not None and weight_f16 is None and skip is None and not _NO_S16_GATHER
             and L.ddnm_conv_gather_s16_supported(ctypes.byref(d)) == 1)
     if s16 or s16g:
         d.weight = weight_s16[0].data_ptr()
         d.acc_scale = 1.0 / (float(weight_s16[1]) * _s16_act_scale())
+        if gn is None or skip is not None:
+            # operand-range guard: a raw operand may have ANY fp32 magnitude; the kernel scales it per image by a power
+            # of two derived on the device from this bound (include/ddnm_hip.h::ddnm_conv_desc::amax_in)
+            if raw_amax is None:
+                raw_amax = amax_bound(*skip) if skip is not None else amax_bound(a_src0, a_src1)
+            d.amax_in = raw_amax.data_ptr()
     if weight_f16 is not None:
         if ksize == 3:
             f16 = L.ddnm_conv3x3_f16_supported(ctypes.byref(d)) == 1
@@ -338,6 +380,10 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         _timer.records.append((variant, flops, e0, e1))
         _timer.shapes.append((B, Ho, Wo, C0 + C1, cout, ksize, stride, int(ups), d.SC0 + d.SC1, gn is not None,
                               res is not None))
+    if _S16_CHECK and (s16 or s16g) and not bool(torch.isfinite(out).all()):
+        raise FloatingPointError(f"split-fp16 launch produced non-finite values (B={B}, {Hin}x{Win}, Cin={C0 + C1}, "
+                                 f"Cout={cout}, k={ksize}): an operand left fp16 range; DDNM_CONV_F32=mfma32 selects the "
+                                 "all-fp32 engine")
     if emit_stats:
         return Act(out, stats, tiles)
     return out
@@ -420,6 +466,8 @@ def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=N
         fused_fin = ws.scale.numel() >= B * cout and L.ddnm_conv16_fuses_fin(ctypes.byref(d)) == 1
         if not fused_fin:
             d.fin_gamma = None
+        else:
+            ws.generation += 1
     stats, tiles = None, 0
     if emit_stats:
         tiles = L.ddnm_conv16_stats_tiles(ctypes.byref(d))
@@ -444,7 +492,7 @@ def conv16(src, weight, cout, ksize, *, src1=None, gn=None, gn_silu=True, bias=N
         flops = 2.0 * B * H * W * cout * (ksize * ksize * d.Cin + d.SC0 + d.SC1)
         _timer.records.append((f"conv16<{ksize}x{ksize}>", flops, e0, e1))
         _timer.shapes.append((B, H, W, d.Cin, cout, ksize, 1, int(ups), d.SC0 + d.SC1, False, res is not None))
-    return Act(out, stats, tiles, gn=(fin[6].scale, fin[6].shift, fin[0]) if fused_fin else None)
+    return Act(out, stats, tiles, gn=(fin[6].scale, fin[6].shift, fin[0], fin[6], fin[6].generation) if fused_fin else None)
 
 
 def conv16_out(src, weight, cout, bias=None, gn=None, gn_silu=True):
@@ -534,6 +582,9 @@ class GroupNormWorkspace:
         self.partial = torch.empty(max_partial_doubles, dtype=torch.float64, device=device)
         self.scale = torch.empty(max_batch * max_channels, dtype=torch.float32, device=device)
         self.shift = torch.empty(max_batch * max_channels, dtype=torch.float32, device=device)
+        # bumped by every launch that writes scale / shift (finalize kernels, the fused `fin` pass of conv16): a consumer
+        # that was handed "already finalized" buffers checks that nobody has overwritten them since (Act.gn)
+        self.generation = 0
 
 
 def gn_nchunk(hw, c):
@@ -543,12 +594,14 @@ def gn_nchunk(hw, c):
     return n
 
 
-def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0, keep=None):
+def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, film_stride=0, keep=None, want_amax=False):
     """(scale, shift) [B][C] such that GN(x)[b,:,c] = x*scale + shift; no normalised tensor is written.
     `film` (rows [s | t], row stride film_stride) folds the FiLM modulation GN(x)*(1+s)+t into the affine.
     src0 / src1 may be tensors or `Act`s; when every source carries conv-epilogue partials the statistics
     come from those (no pass over the activation), otherwise from the stand-alone statistics kernel."""
     # keep: optional dict that receives private copies of (scale, shift, mean_rstd) for a backward pass
+    # want_amax: also return the [B][AMAX_N] operand bound of concat(src0, src1) (a third value), emitted by the same
+    # finalize launch when the statistics come from tile partials (groups == AMAX_N), by amax_bound otherwise
     a0 = src0 if isinstance(src0, Act) else Act(src0)
     a1 = None if src1 is None else (src1 if isinstance(src1, Act) else Act(src1))
     if a0.t.dtype == torch.float16:          # fp16-activation path: statistics always come as tile partials
@@ -561,6 +614,8 @@ def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, fi
     C1 = 0 if src1 is None else src1.shape[3]
     C, HW = C0 + C1, H * W
     sc_buf, sh_buf, mr = ws.scale, ws.shift, None
+    if keep is None:
+        ws.generation += 1
     if keep is not None:
         sc_buf = torch.empty(B * C, dtype=torch.float32, device=src0.device)
         sh_buf = torch.empty(B * C, dtype=torch.float32, device=src0.device)
@@ -569,10 +624,15 @@ def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, fi
     if a0.stats is not None and (a1 is None or a1.stats is not None):
         if sc_buf.numel() < B * C:
             raise ValueError("GroupNorm workspace too small")
-        check(_lib.lib().ddnm_gn_finalize_tiles_f32(_p(a0.stats), a0.tiles, C0, None if a1 is None else _p(a1.stats),
-                                                    0 if a1 is None else a1.tiles, C1, _p(gamma), _p(beta), B, HW,
-                                                    groups, eps, _p(sc_buf), _p(sh_buf), _p(film), film_stride,
-                                                    _p(mr), _stream()), "ddnm_gn_finalize_tiles_f32")
+        amax = None
+        if want_amax and groups == AMAX_N:
+            amax = torch.empty(B * AMAX_N, dtype=torch.float32, device=src0.device)
+        check(_lib.lib().ddnm_gn_finalize_tiles_amax_f32(_p(a0.stats), a0.tiles, C0, None if a1 is None else _p(a1.stats),
+                                                         0 if a1 is None else a1.tiles, C1, _p(gamma), _p(beta), B, HW,
+                                                         groups, eps, _p(sc_buf), _p(sh_buf), _p(film), film_stride,
+                                                         _p(mr), _p(amax), _stream()), "ddnm_gn_finalize_tiles_amax_f32")
+        if want_amax:
+            return sc_buf, sh_buf, (amax if amax is not None else amax_bound(a0, a1))
         return sc_buf, sh_buf
     nchunk = gn_nchunk(HW, C)
     need = B * nchunk * groups * 2
@@ -583,6 +643,8 @@ def group_norm_affine(src0, src1, gamma, beta, eps, ws, groups=32, film=None, fi
           "ddnm_gn_stats_f32")
     check(L.ddnm_gn_finalize_f32(_p(ws.partial), nchunk, _p(gamma), _p(beta), B, HW, C, groups, eps, _p(sc_buf),
                                  _p(sh_buf), _p(film), film_stride, _p(mr), _stream()), "ddnm_gn_finalize_f32")
+    if want_amax:
+        return sc_buf, sh_buf, amax_bound(a0, a1)
     return sc_buf, sh_buf
 
 

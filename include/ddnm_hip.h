@@ -28,7 +28,7 @@ extern "C" {
 #define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
 #define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
 
-int ddnm_version(void);                 /* ABI version, currently 4 (bumped on every struct / prototype change) */
+int ddnm_version(void);                 /* ABI version, currently 5 (bumped on every struct / prototype change) */
 const char* ddnm_build_digest(void);    /* sha256 of the sources + flags this binary was built from (build.py) */
 int ddnm_sizeof(int which);             /* sizeof of 0: ddnm_conv_desc, 1: ddnm_gemm_desc, 2: ddnm_conv16_desc,
                                            3: ddnm_step_scalars as compiled into the binary (-1: unknown index) */
@@ -89,7 +89,21 @@ typedef struct ddnm_conv_desc {
     float acc_scale;        /* ddnm_conv3x3_s16_f32 only: power of two that multiplies the accumulator before bias / residual
                                (undoes the operand pre-scaling of the split form); ignored by the other entry points */
     int32_t reserved0;
+    /* ABI 5 -- operand-range guard of the split forms (ddnm_conv3x3_s16_f32, ddnm_conv_gather_s16_f32; ignored by every
+     * other entry point).  fp16 carries |v| < 65504 only, fp32 -- the arithmetic the reference runs -- does not care, so
+     * operands the kernel reads RAW (no GroupNorm in front: src0 / src1 when gn_scale is NULL, skip0 / skip1 always) are
+     * scaled per launch and image by a power of two derived ON THE DEVICE from an upper bound of their magnitude:
+     *   amax_in = [B][DDNM_AMAX_N] non-negative floats, max_i amax_in[b][i] >= max |raw operand of image b|
+     * (ddnm_gn_finalize_tiles_amax_f32 emits them from the producer's GroupNorm partials for free, ddnm_amax_bound_f32
+     * from partials or from the tensor itself).  The kernel multiplies the raw operand by 2^k, k = 14 - exponent(bound)
+     * (bound lands in [2^14, 2^15): no overflow for ANY fp32 input magnitude, and uniformly tiny tensors keep fp32
+     * grade because hi AND lo become normal fp16 numbers), and the accumulator by 2^-k (exact).  A launch whose main
+     * operand is GroupNorm'd and whose fused shortcut is raw shares one accumulator: k is then clamped to <= 0 (scale
+     * down only) and applied to both operands.  NULL = no scaling (operands must lie within fp16 range). */
+    const float* amax_in;
 } ddnm_conv_desc;
+
+#define DDNM_AMAX_N 32   /* bound words per image (= the GroupNorm group count of both networks) */
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
 /* N-tile (32 or 64 or 128) the kernel will use for this desc: Cout_pad of the packed weight. */
@@ -135,7 +149,8 @@ int ddnm_conv3x3_s16_f32(const ddnm_conv_desc* d, void* stream);
 int ddnm_conv3x3_s16_supported(const ddnm_conv_desc* d);
 int64_t ddnm_conv3x3_s16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv3x3_s16_stats_tiles(const ddnm_conv_desc* d);
-float ddnm_conv3x3_s16_act_scale(void);   /* power of two the kernel multiplies activations with before splitting them */
+float ddnm_conv3x3_s16_act_scale(void);   /* compile-time activation pre-scale: 1 since ABI 5 (the scale is per launch and
+                                             image, derived on the device from ddnm_conv_desc::amax_in) */
 
 /* The same arithmetic for the layers the 3x3 halo kernel does not take, as a per-tap gather (csrc/conv_gather_s16.hip):
  * Downsample's 3x3 stride 2 with (0,1,0,1) padding (guided_diffusion/models.py:61-71), the 1x1 convolutions of the
@@ -280,6 +295,21 @@ int ddnm_gn_finalize_tiles_f32(const float* part0, int32_t tiles_per_img0, int32
                                int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
                                int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,
                                int32_t film_stride, float* mean_rstd, void* stream);
+/* The same launch additionally writes amax_out[b][g] = sqrt(max over the group's (tile, channel) partials of the sum of
+ * squares) >= max |x| over the group's channels: the operand bound of ddnm_conv_desc::amax_in for the launches that read
+ * the same tensor(s) RAW (a ResnetBlock's fused / un-fused nin_shortcut reads what norm1 normalises, models.py:109,
+ * 115-134).  groups must equal DDNM_AMAX_N. */
+int ddnm_gn_finalize_tiles_amax_f32(const float* part0, int32_t tiles_per_img0, int32_t C0, const float* part1,
+                                    int32_t tiles_per_img1, int32_t C1, const float* gamma, const float* beta, int32_t B,
+                                    int32_t HW, int32_t groups, float eps, float* scale, float* shift, const float* film,
+                                    int32_t film_stride, float* mean_rstd, float* amax_out, void* stream);
+/* Stand-alone form for raw operands that no GroupNorm reads first (Downsample / Upsample convolution inputs,
+ * models.py:47-51,61-71; the attention output in front of proj_out, :183-189): out[b][i], i < DDNM_AMAX_N, bounds the
+ * i-th 1/32 slice of image b's data of up to two sources.  kind 0: the fp32 tensor itself, per_image elements per image
+ * (max |x|); kind 1: GroupNorm partials [tiles][C][2] of the tensor, per_image = tiles*C*2 floats (sqrt(max sum of
+ * squares)).  per_image % 4 == 0; src1 may be NULL. */
+int ddnm_amax_bound_f32(const float* src0, int64_t per_image0, int32_t kind0, const float* src1, int64_t per_image1,
+                        int32_t kind1, float* out, int32_t B, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Batched GEMM on MFMA f32:  C = alpha * A * op(B) + beta * D

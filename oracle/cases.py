@@ -46,10 +46,10 @@ def wh_perm(img_dim, seed=SEED + 4):
     return torch.randperm(img_dim ** 2, generator=g)
 
 
-def make_operator(name, img_dim, mask=None):
+def make_operator(name, img_dim, mask=None, ratio=4):
     """Oracle operator objects for the --deg names of guided_diffusion/diffusion.py:451-523."""
     if name == "sr_averagepooling":
-        return O.SuperResolution(3, img_dim, 4)
+        return O.SuperResolution(3, img_dim, ratio)
     if name == "sr_bicubic":
         k = O.bicubic_kernel(4)
         return O.SRConv(k / k.sum(), 3, img_dim, stride=4)
@@ -141,6 +141,15 @@ FULL_CASES = {
     # configs[2] at the per-GPU batch bench.py times (B = 4 selects other conv16 launch plans than B = 1), 10 of the
     # 100 steps: ~40 evaluations of the full net through the reference on CPU
     "c3b4": dict(net="adm", deg="colorization", batch=4, T=10, travel=(1, 1), class_cond=False, record=(1, 5, 8)),
+    # configs[3] / configs[4] at their per-GPU benchmarked batches (B = 4 / B = 8), 10 steps; c4b4 keeps a time-travel
+    # schedule (l = 2, r = 2: 26 iterations) and the repository mask, c5b8 the classifier guidance at B = 8
+    "c4b4": dict(net="adm", deg="inpainting", batch=4, T=10, travel=(2, 2), class_cond=False, record=(1, 13, 24)),
+    "c5b8": dict(net="adm", deg="cs_walshhadamard", batch=8, T=10, travel=(1, 1), class_cond=True, record=(1, 5, 8)),
+    # evaluation.sh:18: `--config celeba_hq.yml --deg sr_averagepooling --deg_scale 16 --sigma_y 0.2 --add_noise`: the
+    # runner doubles sigma_y (diffusion.py:524) and takes ddnm_plus_diffusion (:590); 16x16 patches (n = 256 singular
+    # vectors per patch: the large-ratio branch of the SuperResolution spectral surface)
+    "c2sr16": dict(net="celeba", deg="sr_averagepooling", ratio=16, sigma_y=0.4, batch=2, T=20, travel=(1, 1),
+                   class_cond=False, record=(2, 10, 17)),
 }
 
 

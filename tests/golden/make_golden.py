@@ -24,10 +24,10 @@ from oracle import cases, ref_import, schedule  # noqa: E402
 OPS = ["sr_averagepooling", "sr_bicubic", "colorization", "inpainting", "cs_walshhadamard", "denoising"]
 
 
-def ref_operator(R, name, d, mask=None):
+def ref_operator(R, name, d, mask=None, ratio=4):
     from oracle import operators as O
     if name == "sr_averagepooling":
-        return R.SuperResolution(3, d, 4, "cpu")
+        return R.SuperResolution(3, d, ratio, "cpu")
     if name == "sr_bicubic":
         k = O.bicubic_kernel(4)            # restates diffusion.py:485-499 (checked below)
         return R.SRConv(k / k.sum(), 3, d, "cpu", stride=4)
@@ -363,6 +363,30 @@ def make_spectral():
     np.savez_compressed(os.path.join(HERE, "spectral.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
 
 
+def make_spectral_sr16():
+    """The same surface for SuperResolution at ratio 16 (`--deg sr_averagepooling --deg_scale 16`, evaluation.sh:18: sites of
+    n = 256 entries -- the engine's V / Vt take the GEMM route there), 64 x 64 image, plus Lambda / Lambda_noise at the
+    noisy setting of that line (sigma_y = 0.4 after the runner's doubling): tests/golden/spectral_sr16.npz."""
+    ns = ref_import.load()
+    R = ns.svd_operators
+    d = 64
+    x = cases.operator_input(d, 2)
+    g = torch.Generator().manual_seed(cases.SEED + 32)
+    op = R.SuperResolution(3, d, 16, "cpu")
+    y = op.A(x)
+    z = torch.randn(2, 3 * d * d, generator=g)
+    w = torch.randn(*y.shape, generator=g)
+    e = torch.randn(2, 3 * d * d, generator=g)
+    out = dict(z=z.numpy(), w=w.numpy(), e=e.numpy(), A=y.numpy(), A_pinv=op.A_pinv(w.clone()).numpy(),
+               Vt=op.Vt(x.clone()).numpy(), V=op.V(z.clone()).numpy(), Ut=op.Ut(w.clone()).numpy(), U=op.U(w.clone()).numpy(),
+               add_zeros=op.add_zeros(w.clone()).numpy(), At=op.At(w.clone()).numpy(),
+               A_pinv_eta=op.A_pinv_eta(w.clone(), 0.3).numpy())
+    for tag, (a, st) in {"early": (0.2, 0.97), "late": (0.98, 0.15)}.items():     # both branches of svd_ddnm.py:121-131
+        out[f"Lambda_{tag}"] = op.Lambda(z.clone(), torch.tensor(a), 0.4, torch.tensor(st), 0.85).numpy()
+        out[f"Lambda_noise_{tag}"] = op.Lambda_noise(z.clone(), torch.tensor(a), 0.4, torch.tensor(st), 0.85, e.clone()).numpy()
+    np.savez_compressed(os.path.join(HERE, "spectral_sr16.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+
+
 def make_full(names):
     """--full-adm / --full-c2b8: the FULL BASELINE configurations through the real reference loop
     (functions/svd_ddnm.py:19-78), operators built as guided_diffusion/diffusion.py:451-523 builds them, fp32
@@ -400,8 +424,11 @@ def make_full(names):
                     log_probs = F.log_softmax(logits, dim=-1)
                     selected = log_probs[range(len(logits)), y.view(-1)]
                     return torch.autograd.grad(selected.sum(), x_in)[0] * scale
-        op = ref_operator(R, c["deg"], 256, mask_real if c["deg"] == "inpainting" else None)
+        op = ref_operator(R, c["deg"], 256, mask_real if c["deg"] == "inpainting" else None, ratio=c.get("ratio", 4))
         y = op.A(x_orig)
+        sigma_y = c.get("sigma_y", 0.0)
+        if sigma_y > 0:                                  # --add_noise (diffusion.py:549-551), seeded
+            y = y + sigma_y * torch.randn(y.shape, generator=torch.Generator().manual_seed(cases.SEED + 9))
         times = schedule.jump_times(c["T"], *c["travel"])
         for k in c["record"]:
             assert times[k + 1] < times[k], f"record index {k} of {name} is not a reverse step"
@@ -412,14 +439,18 @@ def make_full(names):
                 inter[k] = x0_t.detach().clone()
         t0 = time.perf_counter()
         with ref_import.cuda_is_cpu(), ref_import.noise_tape(tape, on_call=on_call):
-            xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, cls_fn=cls_fn,
-                                                 classes=None, config=cfg)
+            if sigma_y > 0:                              # diffusion.py:587-590
+                xs, x0s = ns.svd_ddnm.ddnm_plus_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, sigma_y,
+                                                          cls_fn=cls_fn, classes=None, config=cfg)
+            else:
+                xs, x0s = ns.svd_ddnm.ddnm_diffusion(x_T.clone(), ref, cases.betas(), 0.85, op, y, cls_fn=cls_fn,
+                                                     classes=None, config=cfg)
         dt = time.perf_counter() - t0
         x, x0 = xs[0], x0s[0]
         out = dict(x_sub=sub(x, 4), x0_sub=sub(x0, 4), psnr=sampler.psnr(x, x_orig).numpy(),
                    stats=np.array([x.double().mean().item(), x.double().std().item(), x.double().abs().sum().item()]),
                    consistency=np.array([(op.A(x) - y).abs().max().item()]),
-                   record_k=np.array(c["record"]), ref_cpu_seconds=np.array([dt]),
+                   record_k=np.array(c["record"]), ref_cpu_seconds=np.array([dt]), y=(y.numpy() if sigma_y > 0 else np.zeros(0)),
                    ref_cpu_threads=np.array([torch.get_num_threads()]))
         for k, v in inter.items():
             out[f"x0_k{k}_sub"] = sub(v, 4)
@@ -443,11 +474,14 @@ def main():
     ap.add_argument("--deblur-only", action="store_true", help="only (re)generate the deblurring goldens")
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     ap.add_argument("--spectral-only", action="store_true", help="only (re)generate the V / Vt / U / Ut / At goldens")
+    ap.add_argument("--spectral-sr16-only", action="store_true", help="only (re)generate the ratio-16 SuperResolution goldens")
     args = ap.parse_args()
     if args.full_cases:
         return make_full(args.full_cases.split(","))
     if args.spectral_only:
         return make_spectral()
+    if args.spectral_sr16_only:
+        return make_spectral_sr16()
     if args.classifier_only:
         return make_classifier()
     if args.plus_deblur_only:

@@ -11,13 +11,15 @@ def real_mask(golden_dir):
     return torch.from_numpy(bits.reshape(shape).astype(np.int64))
 
 
-def engine_operator(name, d, mask=None, device="cuda"):
+def engine_operator(name, d, mask=None, device="cuda", ratio=4):
     """Engine (HIP) operator for a --deg name, built from the same seeded ingredients as
     oracle.cases.make_operator."""
     from ddnm_amd.functions import svd_operators as E
     from oracle import cases
     if name == "sr_averagepooling":
-        return E.SuperResolution(3, d, 4, device)
+        return E.SuperResolution(3, d, ratio, device)
+    if name == "sr_averagepooling_x16":              # evaluation.sh:18 (`--deg_scale 16`): 256 entries per site
+        return E.SuperResolution(3, d, 16, device)
     if name == "sr_bicubic":
         return E.SRConv(E.bicubic_kernel(4), 3, d, device, stride=4)
     if name == "colorization":

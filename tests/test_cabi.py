@@ -38,7 +38,7 @@ def test_prototypes_match_header():
 
 def test_version_and_error_strings(lib):
     from ddnm_amd import _lib
-    assert lib.ddnm_version() == _lib.ABI_VERSION == 4
+    assert lib.ddnm_version() == _lib.ABI_VERSION == 5
     assert b"shape" in lib.ddnm_error_string(-2)
     assert b"bad argument" in lib.ddnm_error_string(-1)
     assert lib.ddnm_error_string(0) == b"success"
@@ -47,7 +47,9 @@ def test_version_and_error_strings(lib):
 def test_struct_layouts_match_header():
     from ddnm_amd._lib import ConvDesc, GemmDesc, StepScalars
     # 9 pointers + 16 int32 + pointer + int64 + 2 int32 + pointer + 3 pointers + 2 int32 + float + int32 (8-byte aligned)
-    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8
+    # + the operand-bound pointer of ABI 5
+    assert ctypes.sizeof(ConvDesc) == 9 * 8 + 16 * 4 + 8 + 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8
+    assert ConvDesc.amax_in.offset == ctypes.sizeof(ConvDesc) - 8
     assert ConvDesc.workspace.offset == 9 * 8 + 16 * 4
     assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4 + 2 * 4
     assert ctypes.sizeof(StepScalars) == 24

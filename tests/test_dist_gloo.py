@@ -61,3 +61,28 @@ def test_shard_range_partitions_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _world1_worker(rank, port, out_dir):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ddnm_amd import dist as ddist
+    r, lr, w = ddist.init(backend="gloo")           # a launcher-started world of ONE still gets a process group ...
+    assert (r, w) == (0, 1) and dist.is_initialized() and ddist.backend_name() == "gloo"
+    x = torch.arange(2 * 3 * 4 * 4, dtype=torch.float32).reshape(2, 3, 4, 4)
+    calls = []
+    orig = dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), orig(*a, **k))[1]
+    full = ddist.gather_images(x)                   # ... and its collectives really run (the 8-GPU code path)
+    dist.all_gather = orig
+    assert calls == ["all_gather"] and torch.equal(full, x)
+    assert ddist.reduce_scalar(3.5, "cpu", "sum") == 3.5 and ddist.broadcast_flag(True) is True
+    ddist.barrier()
+    ddist.shutdown()
+    assert not dist.is_initialized()
+    assert ddist.gather_images(x) is x              # without a group: the identity, no collective
+    open(os.path.join(out_dir, "ok"), "w").write("ok")
+
+
+def test_world_of_one_under_a_launcher_runs_its_collectives(tmp_path):
+    mp.spawn(_world1_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "ok")

@@ -381,6 +381,33 @@ def test_operator_svd_surface(hip, name, golden_dir):
         assert rel(op.U(gw).cpu(), torch.from_numpy(gold[f"{name}_U"])) == 0.0
 
 
+def test_superresolution_ratio16_surface(hip, golden_dir):
+    """SuperResolution at ratio 16 (evaluation.sh:18: `--deg sr_averagepooling --deg_scale 16`): 256 entries per site, so
+    V / Vt run as ONE MFMA GEMM over all sites (ddnm_bgemm_f32) instead of the register-resident site kernel; every entry
+    point against the outputs of the reference class (functions/svd_operators.py:479-623, tests/golden/spectral_sr16.npz)."""
+    from tests.helpers import engine_operator
+    from oracle import cases
+    d, B = 64, 2
+    op = engine_operator("sr_averagepooling_x16", d)
+    g = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/spectral_sr16.npz").items()}
+    x = cases.operator_input(d, B).cuda()
+    xf = x.reshape(B, -1)
+    z, w, e = g["z"].cuda(), g["w"].cuda(), g["e"].cuda()
+    assert rel(op.A(x), g["A"]) < 2e-6 and rel(op.A_pinv(w), g["A_pinv"]) < 2e-6
+    assert rel(op.V(op.Vt(x)), xf) < 2e-6 and rel(op.Vt(op.V(xf)), xf) < 2e-6
+    s = op.singulars().float()
+    n = s.numel()
+    assert rel(op.U(s * op.Vt(x)[:, :n]), op.A(x)) < 2e-5
+    # the reference's V_small comes from the same LAPACK call on a 1 x 256 row; compare the full vectors too
+    assert rel(op.Vt(x), g["Vt"]) < 2e-5 and rel(op.V(z), g["V"]) < 2e-5
+    assert rel(op.U(w), g["U"]) == 0.0 and rel(op.Ut(w), g["Ut"]) == 0.0
+    assert rel(op.add_zeros(w), g["add_zeros"]) == 0.0
+    assert rel(op.At(w), g["At"]) < 2e-5 and rel(op.A_pinv_eta(w, 0.3), g["A_pinv_eta"]) < 2e-5
+    for tag, (a, st) in {"early": (0.2, 0.97), "late": (0.98, 0.15)}.items():
+        assert rel(op.Lambda(z, a, 0.4, st, 0.85), g[f"Lambda_{tag}"]) < 1e-5
+        assert rel(op.Lambda_noise(z, a, 0.4, st, 0.85, e), g[f"Lambda_noise_{tag}"]) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,H,gn", [(2, 128, 64, True), (1, 64, 32, False), (3, 128, 32, True)])
 def test_small_cout_output_conv(hip, B, C, H, gn):
     """conv_out of the celeba Model (128 -> 3, GroupNorm + swish fused, NCHW result) on the vector-ALU kernel."""

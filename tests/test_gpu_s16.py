@@ -21,7 +21,8 @@ def _make(B, C0, C1, Cout, H, ups, gn, res, skip, badd=False, seed=0, wscale=Non
              w=rn(Cout, cin, 3, 3) * (wscale if wscale is not None else 1.0 / (3.0 * cin ** 0.5)), bias=rn(Cout),
              sc=rn(B, cin) * 0.3 + 1.0 if gn else None, sh=rn(B, cin) * 0.3 if gn else None,
              r=rn(B, Ho, Ho, Cout) * 2.0 if res else None, sk=rn(B, H, H, 64) * 2.0 if skip else None,
-             wsk=rn(Cout, 64, 1, 1) * 0.1 if skip else None, badd=rn(B, Cout) if badd else None, ups=ups, Cout=Cout)
+             wsk=rn(Cout, 64, 1, 1) * 0.1 if skip else None, badd=rn(B, Cout) if badd else None, ups=ups, Cout=Cout,
+             amax=None)
     return t
 
 
@@ -59,7 +60,8 @@ def _run(t, split):
     return ops.conv2d(t["a"], w32, t["Cout"], 3, src1=t["b"], bias=t["bias"], res=t["r"], gn=gn, gn_silu=True,
                       badd=t["badd"], badd_stride=(t["Cout"] if t["badd"] is not None else 0),
                       ups=bool(t["ups"]), emit_stats=True, weight_s16=s16,
-                      skip=None if t["sk"] is None else (t["sk"], None), skip_weight=wsk32), B
+                      skip=None if t["sk"] is None else (t["sk"], None), skip_weight=wsk32,
+                      raw_amax=t["amax"] if split else None), B
 
 
 def _errors(t):
@@ -118,14 +120,125 @@ def test_split_kernel_badly_scaled_operands(wscale, ascale):
     assert e[True][0] <= 1.25 * e[False][0] + 2e-8
 
 
-@pytest.mark.parametrize("ascale,bound", [(0.02, 3e-6), (2e-4, 3e-4)])
-def test_split_kernel_uniformly_tiny_operand_degrades_gracefully(ascale, bound):
-    # a tensor that is tiny everywhere sits in the subnormal range of `lo`: the absolute error stays <= 2^-25 per
-    # element, the relative error of the result grows accordingly (documented domain: csrc/conv_common.h)
+# ------------------------------------------------------------------ operand-range guard (ddnm_conv_desc::amax_in, ABI 5)
+@pytest.mark.parametrize("ascale", [0.02, 2e-4, 1e-5, 1e-9, 1e5, 3e7, 1e12])
+def test_raw_operand_of_any_magnitude_stays_fp32_grade(ascale):
+    # fp16 carries |v| < 65504 and loses relative precision below ~2^-14; the reference runs this network in fp32, where
+    # neither limit exists.  A raw operand is therefore scaled per launch and image by a power of two derived on the
+    # device from its bound: uniformly tiny tensors (which kept 1e-4 ... 1e-6 until round 3) and tensors far beyond the
+    # fp16 range (inf until round 3) both match fp64 like the fp32 MFMA kernel does.
     t = _make(2, 128, 0, 128, 32, 0, 0, 0, 0, seed=3, wscale=0.05, ascale=ascale)
     t["bias"].zero_()
     e = _errors(t)
-    assert e[True][0] < bound, e[True][0]
+    assert torch.isfinite(e[True][2].t).all()
+    assert e[True][0] < 8e-7, e[True][0]
+    assert e[True][0] <= 1.25 * e[False][0] + 2e-8
+
+
+def test_operand_scale_is_per_image():
+    # image 0 ~ 1e5, image 1 ~ 1e-4 in ONE launch: each image gets its own power of two
+    t = _make(2, 128, 0, 128, 32, 0, 0, 0, 0, seed=4, wscale=0.05, ascale=1.0)
+    t["a"][0] *= 1e5
+    t["a"][1] *= 1e-4
+    t["bias"].zero_()
+    y = _ref64(t)
+    act, _ = _run(t, True)
+    for b in range(2):
+        assert ((act.t[b].double() - y[b]).norm() / y[b].norm()).item() < 8e-7
+
+
+@pytest.mark.parametrize("form", ["upsample", "fused_shortcut_huge", "fused_shortcut_tiny", "downsample", "proj_out",
+                                  "nin_shortcut_concat"])
+@pytest.mark.parametrize("mag", [1e5, 1e-5])
+def test_every_raw_operand_launch_form_is_guarded(form, mag):
+    """The raw-operand launches of the celeba `Model` (models.py:47-51 Upsample, :61-71 Downsample, :109 nin_shortcut fused
+    into conv2 or on its own, :183-189 proj_out) with an input of magnitude 1e5 / 1e-5: finite and fp32 grade against fp64.
+    The bound comes from the producer's GroupNorm partials (an `Act`), from the finalize launch, or from the tensor."""
+    from ddnm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(21)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    if form == "upsample":
+        t = _make(2, 128, 0, 128, 16, 1, 0, 0, 0, seed=5, ascale=mag)
+    elif form.startswith("fused_shortcut"):
+        t = _make(2, 128, 0, 256, 32, 0, 1, 0, 1, seed=6)
+        t["sk"] = t["sk"] * (mag if form.endswith("huge") else 1.0 / max(mag, 1.0 / mag))
+    if form in ("upsample", "fused_shortcut_huge", "fused_shortcut_tiny"):
+        e = _errors(t)
+        assert torch.isfinite(e[True][2].t).all()
+        assert e[True][0] < 8e-7 and e[True][0] <= 1.25 * e[False][0] + 2e-8, e
+        return
+    B, C0, C1, Cout, H, k, stride, res = {"downsample": (2, 128, 0, 128, 32, 3, 2, 0), "proj_out": (2, 512, 0, 512, 16, 1, 1, 1),
+                                          "nin_shortcut_concat": (2, 256, 256, 256, 16, 1, 1, 0)}[form]
+    a, b = rn(B, H, H, C0) * mag, (rn(B, H, H, C1) * mag if C1 else None)
+    w = rn(Cout, C0 + C1, k, k) / (k * (C0 + C1) ** 0.5)
+    r = rn(B, H // stride, H // stride, Cout) * mag if res else None
+    x = (a if b is None else torch.cat([a, b], 3)).double().permute(0, 3, 1, 2)
+    y = F.conv2d(F.pad(x, (0, 1, 0, 1)), w.double(), stride=2) if stride == 2 else F.conv2d(x, w.double(), padding=k // 2)
+    y = y.permute(0, 2, 3, 1)
+    if res:
+        y = y + r.double()
+    sw = ops.s16_weight_scale(w)
+    # the downsample's input arrives as an `Act` with its producer's GroupNorm partials (what the network passes)
+    src = a
+    if form == "downsample":
+        ident = torch.zeros(C0, C0, 1, 1, device=DEV)
+        ident[torch.arange(C0), torch.arange(C0), 0, 0] = 1.0
+        src = ops.conv2d(a, ops.pack_conv_weight(ident), C0, 1, emit_stats=True)          # fp32 kernel: a copy + partials
+        assert src.stats is not None and torch.equal(src.t, a)
+    act = ops.conv2d(src, ops.pack_conv_weight(w), Cout, k, src1=b, res=r, stride=stride, pad=(0 if stride == 2 else k // 2),
+                     out_hw=(H // stride, H // stride), emit_stats=True, weight_s16=(ops.pack_conv_weight_s16(w, sw), sw, None))
+    assert torch.isfinite(act.t).all()
+    assert ((act.t.double() - y).norm() / y.norm()).item() < 8e-7
+
+
+def test_operand_bound_kernels():
+    """ddnm_amax_bound_f32 (tensor / partials form) and the bound emitted by ddnm_gn_finalize_tiles_amax_f32: upper
+    bounds of max |x| per image, tight to the tile size (sqrt of a per-(tile, channel) sum of squares)."""
+    from ddnm_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(8)
+    B, H, C = 3, 32, 128
+    x = torch.randn(B, H, H, C, device=DEV, generator=g) * torch.tensor([1e-3, 1.0, 4e4], device=DEV)[:, None, None, None]
+    true = x.abs().amax((1, 2, 3))
+    raw = ops.amax_bound(x).view(B, ops.AMAX_N).amax(1)
+    assert torch.equal(raw, true)                                        # tensor form: the exact maximum
+    ident = torch.zeros(C, C, 1, 1, device=DEV)
+    ident[torch.arange(C), torch.arange(C), 0, 0] = 1.0
+    act = ops.conv2d(x, ops.pack_conv_weight(ident), C, 1, emit_stats=True)
+    assert act.stats is not None
+    st = ops.amax_bound(act).view(B, ops.AMAX_N).amax(1)
+    assert bool((st >= true).all()) and bool((st <= true * 16.1).all()), (st, true)      # tiles of <= 256 pixels
+    both = ops.amax_bound(act, x * 3.0).view(B, ops.AMAX_N).amax(1)     # two sources, mixed forms
+    assert bool((both >= 3.0 * true).all()) and bool((both <= true * 16.1).all())
+    ws = ops.GroupNormWorkspace(DEV, B, C, 1)
+    gam, bet = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    sc, sh, am = ops.group_norm_affine(act, None, gam, bet, 1e-6, ws, want_amax=True)
+    sc0, sh0 = (t.clone() for t in (sc[:B * C], sh[:B * C]))
+    sc1, sh1 = ops.group_norm_affine(act, None, gam, bet, 1e-6, ws)
+    assert torch.equal(sc0, sc1[:B * C]) and torch.equal(sh0, sh1[:B * C])       # the affine itself is unchanged
+    fin = am.view(B, ops.AMAX_N)
+    per_group = x.abs().view(B, H * H, 32, C // 32).amax((1, 3))
+    assert bool((fin >= per_group).all()) and bool((fin.amax(1) <= true * 16.1).all())
+
+
+def test_split_entry_points_refuse_a_raw_operand_without_bound():
+    import ctypes
+    from ddnm_amd import _lib, ops
+    t = _make(1, 128, 0, 128, 16, 0, 0, 0, 0)
+    sw = ops.s16_weight_scale(t["w"])
+    w16 = ops.pack_conv_weight_s16(t["w"], sw)
+    out = torch.empty(1, 16, 16, 128, device=DEV)
+    for fn, k in ((_lib.lib().ddnm_conv3x3_s16_f32, 3), (_lib.lib().ddnm_conv_gather_s16_f32, 1)):
+        d = _lib.ConvDesc()
+        d.src0, d.weight, d.out = t["a"].data_ptr(), w16.data_ptr(), out.data_ptr()
+        d.B, d.Hin, d.Win, d.C0, d.Cout, d.ksize, d.stride, d.pad, d.Ho, d.Wo = 1, 16, 16, 128, 128, k, 1, k // 2, 16, 16
+        d.acc_scale = 1.0 / sw
+        if k == 1:
+            w1 = ops.pack_conv_weight_s16(t["w"][:, :, 1:2, 1:2].contiguous(), sw)
+            d.weight = w1.data_ptr()
+        assert fn(ctypes.byref(d), ops._stream()) == -1                   # DDNM_E_BADARG: no silent overflow path
+        d.amax_in = ops.amax_bound(t["a"]).data_ptr()
+        assert fn(ctypes.byref(d), ops._stream()) == 0
+    torch.cuda.synchronize()
 
 
 def test_fp16_mfma_honours_subnormal_inputs():
@@ -135,6 +248,7 @@ def test_fp16_mfma_honours_subnormal_inputs():
     t = _make(1, 128, 0, 128, 16, 0, 0, 0, 0, seed=5, ascale=1.0)
     v = 2.0 ** -6 * (1 + 2.0 ** -12) / sa                      # pre-scaled: hi = 2^-6, lo = 2^-18 (subnormal in fp16)
     t["a"].fill_(v)
+    t["amax"] = torch.full((ops.AMAX_N,), 2.0 ** 14, device=DEV)   # a bound in [2^14, 2^15): operand scale 2^0
     t["w"].fill_(0.0)
     t["w"][:, :, 1, 1] = 1.0 / 128                              # centre tap: out = mean over channels = the value itself
     t["bias"].zero_()

@@ -1,0 +1,71 @@
+"""The counted `s_waitcnt vmcnt(N)` waits of the LDS-DMA convolution kernels, checked against the ISSUE ORDER in the gfx950
+ISA that hipcc actually emits (tools/isa_waits.py replays the request stream of every kernel instance's main loop).
+
+The headline kernel (conv_igemm_f16.hip, split form) and the gather form keep two weight tiles in flight by LDS-DMA and wait
+for the older one with an immediate that equals the number of requests issued behind it; a request the compiler (or an
+edit) moves across a DMA request makes the wait return while the tile is still landing -- silently wrong numbers.  The
+loops are written with a branch-free request stream so that the replay is exact; the last test moves one request in a
+copy of the source and demands that the check fails.  CPU only (hipcc cross-compiles)."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_waits  # noqa: E402
+
+CSRC = isa_waits.CSRC
+
+
+@pytest.fixture(scope="module")
+def halo_asm(tmp_path_factory):
+    return isa_waits.compile_isa(os.path.join(CSRC, "conv_igemm_f16.hip"), str(tmp_path_factory.mktemp("isa") / "f16.s"))
+
+
+def test_halo_kernel_waits_match_the_issue_order(halo_asm):
+    res = isa_waits.analyse(halo_asm, r"conv3x3_halo_f16_kernel", min_barriers=9, depth=2)
+    # <4,2,2,2, SRC16, SPLIT, ASCALE>: fp16 operands (fp32 source), fp16 source, split, split + operand scale
+    assert len(res) == 4, list(res)
+    for name, r in res.items():
+        assert r["barriers"] == 9, (name, r)                         # one barrier per tap, taps unrolled
+        assert r["groups"] == [2] * 9, (name, r)                     # BR = 2 LDS-DMA requests per wave and weight tile
+        assert len(r["waits"]) == 9, (name, r)
+        for tap, (n, behind) in enumerate(r["waits"]):
+            assert n == behind, f"{name}: wait #{tap} has vmcnt({n}) but {behind} requests were issued behind the tile"
+    # the split instances: HR = 6 halo slots in two halves of 3 (+ 2 GroupNorm vectors with the first half)
+    split = [r for n, r in res.items() if "Lb0ELb1E" in n]
+    assert len(split) == 2
+    for r in split:
+        assert sorted(n for n, _ in r["waits"]) == [2, 2, 2, 2, 2, 5, 5, 7, 7]
+
+
+def test_gather_kernel_waits_match_the_issue_order(tmp_path):
+    asm = isa_waits.compile_isa(os.path.join(CSRC, "conv_gather_s16.hip"), str(tmp_path / "gs.s"))
+    res = isa_waits.analyse(asm, r"conv_gather_s16_kernel", min_barriers=4, depth=2)
+    assert len(res) == 2
+    for name, r in res.items():
+        ar_br = {"Li2ELi2ELi2ELi2E": (4, 4), "Li2ELi2ELi1ELi1E": (2, 2)}[re.search(r"kernelI(\w+?)Ev", name).group(1)]
+        for n, behind in r["waits"]:
+            assert n == behind == ar_br[0] + 2 + ar_br[1], (name, r)   # AR gathers + 2 GroupNorm vectors + BR DMA requests
+        assert set(r["groups"]) == {ar_br[1]}
+
+
+def test_the_check_fails_when_a_request_is_moved(tmp_path):
+    """Mutation: request the next chunk's first halo half BEFORE tap 0's weight-tile DMA instead of behind it.  The wait of
+    tap 2 (vmcnt(7)) then leaves tap 0's tile among the 7 youngest requests: the replay must flag it."""
+    src = open(os.path.join(CSRC, "conv_igemm_f16.hip")).read()
+    issue = "                issue_step(step + 2, cur >= 1 ? cur - 1 : NWB - 1);"
+    moved = "                if (tap == 0) prefetch_halo_part(nchunk, 0, HSPLIT, more);\n"
+    assert src.count(issue) == 1 and src.count(moved) == 1
+    mut = src.replace(moved, "")
+    mut = mut.replace(issue, "                if (tap == 0) prefetch_halo_part(more ? chunk + 1 : chunk, 0, HSPLIT, more);\n"
+                             "                asm volatile(\"\" ::: \"memory\");\n                __builtin_amdgcn_sched_barrier(0);\n" + issue)
+    p = tmp_path / "conv_igemm_f16_mut.hip"
+    p.write_text(mut)
+    asm = isa_waits.compile_isa(str(p), str(tmp_path / "mut.s"), extra=["-I", CSRC])
+    res = isa_waits.analyse(asm, r"conv3x3_halo_f16_kernelILi4ELi2ELi2ELi2ELb0ELb1ELb0E", min_barriers=9, depth=2)
+    (r,) = res.values()
+    bad = [(n, behind) for n, behind in r["waits"] if n != behind]
+    assert bad and any(n > behind for n, behind in bad), r

@@ -354,3 +354,20 @@ def test_inpainting_real_constructor_small(seed):
     y = ref.A(x)
     assert torch.equal(orc.A(x), y)
     assert torch.equal(orc.A_pinv(y).reshape(2, -1), ref.A_pinv(y.clone()).reshape(2, -1))
+
+
+def test_oracle_superresolution_ratio16_golden(golden_dir):
+    """The oracle's SuperResolution at ratio 16 (evaluation.sh:18) against the reference class
+    (functions/svd_operators.py:479-623; tests/golden/spectral_sr16.npz from make_golden.py --spectral-sr16-only)."""
+    import numpy as np
+    g = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/spectral_sr16.npz").items()}
+    op = cases.make_operator("sr_averagepooling", 64, ratio=16)
+    x = cases.operator_input(64, 2)
+
+    def r(a, b):
+        return ((a.double().reshape(2, -1) - b.double()).norm() / b.double().norm()).item()
+    assert r(op.A(x), g["A"]) < 1e-6 and r(op.A_pinv(g["w"]), g["A_pinv"]) < 1e-6
+    for tag, (a, st) in {"early": (0.2, 0.97), "late": (0.98, 0.15)}.items():
+        assert r(op.Lambda(g["z"].clone(), torch.tensor(a), 0.4, torch.tensor(st), 0.85), g[f"Lambda_{tag}"]) < 1e-6
+        assert r(op.Lambda_noise(g["z"].clone(), torch.tensor(a), 0.4, torch.tensor(st), 0.85, g["e"].clone()),
+                 g[f"Lambda_noise_{tag}"]) < 1e-6
