@@ -185,6 +185,7 @@ PROTOTYPES = {
     "ddnm_site_matmul_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64, c_int64, c_int64,
                                        c_int32, c_void_p]),
     "ddnm_mul_planes_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
+    "ddnm_fill_f32": (c_int32, [c_void_p, c_int64, c_float, c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_op_upsample_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

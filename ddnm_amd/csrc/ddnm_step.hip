@@ -249,6 +249,17 @@ extern "C" int ddnm_renoise_f32(const float* x0, const float* noise, float* xt_n
     return 0;
 }
 
+// out[i] = value (zero padding rows of token matrices, cleared accumulators): keeps ATen fill kernels off the path
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ out, int64_t n, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = value;
+}
+
+extern "C" int ddnm_fill_f32(float* out, int64_t n, float value, void* stream) {
+    if (!out || n <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(fill_kernel, GRID_1D(n), dim3(256), 0, (hipStream_t)stream, out, n, value);
+    return 0;
+}
+
 // ================================================================ stand-alone operators
 __global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                                                       int r, int64_t total) {

@@ -90,6 +90,17 @@ def _guided_eps(et, grad, coef):
     return out
 
 
+def _step_tables(times, skip, n, device, with_classes):
+    """Per-run device constants of the loop: one row [n] of the float timestep per distinct reverse-step time (the
+    reference builds `torch.ones(n) * i` every step, svd_ddnm.py:40) and the constant class vector (:50).  ONE host-to-
+    device copy per run; the loop then only takes views -- no fill kernel (and no other ATen arithmetic) per step."""
+    uniq = sorted({a * skip for a, c in zip(times[:-1], times[1:]) if c < a})
+    table = torch.tensor([[float(v)] * n for v in uniq], dtype=torch.float32).to(device, non_blocking=False) if uniq else None
+    index = {v: k for k, v in enumerate(uniq)}
+    cls = torch.tensor([class_num] * n, dtype=torch.long).to(device) if with_classes else None
+    return (lambda i: table[index[i]]), cls
+
+
 _SIDE_STREAMS = {}
 
 
@@ -111,10 +122,11 @@ class _GuidanceAhead:
     waits on an event right before it combines the two.  Same kernels, same inputs, same results; only the order in
     which two independent launch sequences reach the GPU changes.  DDNM_CLS_OVERLAP=0 restores the serial order."""
 
-    def __init__(self, cls_fn, x, n, t_values):
+    def __init__(self, cls_fn, x, n, t_values, t_of=None, cls=None):
         import collections
         import os
         self.cls_fn, self.x, self.n = cls_fn, x, n
+        self.t_of, self.cls = t_of, cls
         self.t_values, self.pos = t_values, 0
         self.serial = os.environ.get("DDNM_CLS_OVERLAP") == "0"
         self.queue = collections.deque()
@@ -134,8 +146,11 @@ class _GuidanceAhead:
         tv = self.t_values[self.pos]
         self.pos += 1
         with torch.cuda.stream(self.side):
-            t = torch.full((self.n,), float(tv), device=self.x.device, dtype=torch.float32)
-            cls = torch.full((self.n,), class_num, dtype=torch.long, device=self.x.device)
+            if self.t_of is not None:        # views of the per-run tables (built on the main stream before this one forked)
+                t, cls = self.t_of(tv), self.cls
+            else:
+                t = torch.full((self.n,), float(tv), device=self.x.device, dtype=torch.float32)
+                cls = torch.full((self.n,), class_num, dtype=torch.long, device=self.x.device)
             g = self.cls_fn(self.x, t, cls)
             ev = torch.cuda.Event()
             ev.record(self.side)
@@ -199,8 +214,9 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
     have_x0 = False
     guide = None
     with torch.no_grad(), contextlib.ExitStack() as _stack:
+        t_of, cls_const = _step_tables(times, skip, n, x.device, cls_fn is not None)
         if cls_fn is not None:
-            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
+            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a], t_of, cls_const)
             _stack.callback(guide.close)         # also when the loop raises: the main stream re-joins the side stream
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
@@ -210,11 +226,11 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
             out = bufs[k & 1]
             if j < i:      # reverse step
                 at = alpha(i)
-                t = torch.full((n,), float(i), device=x.device, dtype=torch.float32)
+                t = t_of(i)
                 if cls_fn is None:
                     et = model(xt, t)
                 else:
-                    cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
+                    cls = cls_const
                     eps = model(xt, t, cls)
                     et = _guided_eps(eps, guide.grad(i, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:
@@ -264,8 +280,9 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
     have_x0 = False
     guide = None
     with torch.no_grad(), contextlib.ExitStack() as _stack:
+        t_of, cls_const = _step_tables(times, skip, n, x.device, cls_fn is not None)
         if cls_fn is not None:
-            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a])
+            guide = _GuidanceAhead(cls_fn, x, n, [a * skip for a, c in zip(times[:-1], times[1:]) if c < a], t_of, cls_const)
             _stack.callback(guide.close)         # also when the loop raises: the main stream re-joins the side stream
         for k, (i, j) in enumerate(zip(times[:-1], times[1:])):
             i, j = i * skip, j * skip
@@ -275,11 +292,11 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
             out = bufs[k & 1]
             if j < i:
                 at = alpha(i)
-                t = torch.full((n,), float(i), device=x.device, dtype=torch.float32)
+                t = t_of(i)
                 if cls_fn is None:
                     et = model(xt, t)
                 else:
-                    cls = torch.full((n,), class_num, dtype=torch.long, device=x.device)
+                    cls = cls_const
                     eps = model(xt, t, cls)
                     et = _guided_eps(eps, guide.grad(i, t, cls), float((1 - at).sqrt()))
                 if et.size(1) == 6:

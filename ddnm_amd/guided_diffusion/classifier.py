@@ -322,7 +322,7 @@ class EncoderUNetModel:
         Mp = (B * T + 63) // 64 * 64
         X = torch.empty(Mp, C, dtype=torch.float32, device=x.device)
         if Mp > B * T:
-            X[B * T:].zero_()
+            ops.fill_(X[B * T:], 0.0)
         check(L.ddnm_pool_tokens_f32(_p(h.t), _p(gn[0]), _p(gn[1]), _p(w["pool.pos"]), _p(X), B, HW, C, ops._stream()),
               "ddnm_pool_tokens_f32")
         qkv = torch.empty(Mp, 3 * C, dtype=torch.float32, device=x.device)
@@ -412,7 +412,7 @@ class EncoderUNetModel:
         dqkv = torch.empty_like(qkv)                     # [Mp, 3C]: B*T token rows + zero padding rows (see forward)
         Mp = qkv.shape[0]
         if Mp > B * T:
-            dqkv[B * T:].zero_()
+            ops.fill_(dqkv[B * T:], 0.0)
         check(L.ddnm_pool_attn_bwd_f32(_p(qkv), _p(P), _p(da0), _p(dqkv), B, T, C, nh, ops._stream()),
               "ddnm_pool_attn_bwd_f32")
         dX = torch.empty(Mp, C, dtype=torch.float32, device=x.device)

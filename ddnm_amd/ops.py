@@ -782,6 +782,13 @@ def step_combine(x0, proj, apy, noise, et, s, out=None):
     return out
 
 
+def fill_(t, value=0.0):
+    """t[...] = value for a contiguous fp32 tensor (or contiguous slice) through ddnm_fill_f32."""
+    if t.numel():
+        check(_lib.lib().ddnm_fill_f32(_p(_f32c(t, "t")), t.numel(), float(value), _stream()), "ddnm_fill_f32")
+    return t
+
+
 def renoise(x0, noise, a, b, out=None):
     out = torch.empty_like(x0) if out is None else out
     check(_lib.lib().ddnm_renoise_f32(_p(x0), _p(noise), _p(out), x0.numel(), a, b, _stream()), "ddnm_renoise_f32")

@@ -439,6 +439,8 @@ int ddnm_axpby_f32(const float* x, const float* y, float* out, int64_t n, float 
 /* out[b][i] = a*x[b*x_bstride + i] + b*y[b*chw + i]  (guided eps: eps[:, :3] - sqrt(1-abar)*grad, svd_ddnm.py:51-52) */
 int ddnm_axpby_strided_f32(const float* x, int64_t x_bstride, const float* y, float* out, int32_t B, int64_t chw,
                            float a, float b, void* stream);
+/* out[i] = value for i < n (padding rows of token matrices; replaces tensor.zero_() / fill_() on the path). */
+int ddnm_fill_f32(float* out, int64_t n, float value, void* stream);
 /* out = (m ? cx_m : cx_n)*x + (m ? cy_m : cy_n)*y with m = mask[plane % planes_mask][p] != 0 (mask NULL: all measured):
  * Lambda / Lambda_noise of Inpainting (svd_operators.py:361-439), spectral weights of WalshHadamardCS (:253-320). */
 int ddnm_mask_mix_f32(const float* x, const float* y, const float* mask, int32_t planes_mask, int64_t plane_elems,
