@@ -69,3 +69,21 @@ def test_the_check_fails_when_a_request_is_moved(tmp_path):
     (r,) = res.values()
     bad = [(n, behind) for n, behind in r["waits"] if n != behind]
     assert bad and any(n > behind for n, behind in bad), r
+
+
+def test_conv16_k_loops_issue_only_lds_dma(tmp_path):
+    """conv16's request stream is data dependent (the halo pieces a wave fetches, the tail of a split-K slice), so its
+    counted waits follow run-time bookkeeping (`pend` / `ahead`) instead of compile-time constants.  What that bookkeeping
+    needs from the compiler: every request inside a K loop is an LDS-DMA (side-effecting: LLVM keeps them in program
+    order, weight tile last) and none is a register load, which hipcc is free to sink across a DMA request -- and the
+    immediates are 0, one or two request groups (GRP = halo groups per wave + 4 weight requests)."""
+    asm = isa_waits.compile_isa(os.path.join(CSRC, "conv16.hip"), str(tmp_path / "c16.s"))
+    res = isa_waits.dma_only_loops(asm, r"conv16_kernel")
+    assert len(res) == 6, list(res)
+    grp = {"Li9ELi1ELi1E": None, "Li9ELi4ELi4E": None, "Li9ELi2ELi4E": 4, "Li1ELi4ELi4E": None, "Li1ELi2ELi4E": 6, "Li1ELi1ELi4E": 5}
+    for name, (n_loops, n_dma, n_reg, imm) in res.items():
+        key = re.search(r"kernelI(\w+?)Ev", name).group(1)
+        assert n_loops >= 1 and n_dma > 0, (name, n_loops, n_dma)
+        assert n_reg == 0, f"{name}: {n_reg} register load(s) inside a K loop"
+        allowed = {0} if grp[key] is None else {0, grp[key], 2 * grp[key]}
+        assert set(imm) <= allowed, (name, imm, allowed)

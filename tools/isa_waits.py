@@ -192,3 +192,46 @@ if __name__ == "__main__":
         asm = compile_isa(os.path.join(CSRC, src), os.path.join(td, "k.s"), sys.argv[5:])
     for k, v in analyse(asm, name_re, nb, depth).items():
         print(k, v)
+
+
+def k_loops(lines):
+    """Innermost backward-branch regions that hold MFMAs, a barrier, LDS-DMA requests and no store: the K loops."""
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [_LABEL.match(l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = _BRANCH.match(l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            a, b = labels[m.group(1)], i
+            reg = lines[a:b + 1]
+            if any("v_mfma" in x for x in reg) and any(x.startswith("\ts_barrier") for x in reg) \
+                    and any(_REQ.match(x) and re.search(r"\blds\b", x) for x in reg) \
+                    and not any(re.match(r"\t(global|buffer)_store", x) for x in reg):
+                loops.append((a, b))
+    return [(a, b) for (a, b) in loops if not any((c, d) != (a, b) and a <= c and d <= b for (c, d) in loops)]
+
+
+def dma_only_loops(asm, name_re):
+    """For kernels whose request stream is data dependent (conv16: the halo pieces a wave fetches, the tail of a slice) the
+    counted waits are kept correct by run-time bookkeeping (`pend` / `ahead`) that assumes ONE thing about the ISA: every
+    request inside the K loops is an LDS-DMA -- a side-effecting instruction LLVM keeps in program order -- and never a
+    register load, which the compiler is free to move across a DMA request (the hazard the halo kernel's replay guards
+    against).  Returns {kernel: (number of K loops, DMA requests, register loads, sorted vmcnt immediates)}."""
+    out = {}
+    for name, lines in kernels(asm).items():
+        if not re.search(name_re, name):
+            continue
+        loops = k_loops(lines)
+        n_dma = n_reg = 0
+        imm = set()
+        for a, b in loops:
+            for l in lines[a:b + 1]:
+                if _REQ.match(l):
+                    if re.search(r"\blds\b", l):
+                        n_dma += 1
+                    else:
+                        n_reg += 1
+                w = _WAIT.match(l)
+                if w and _VM.search(w.group(1)):
+                    imm.add(int(_VM.search(w.group(1)).group(1)))
+        out[name] = (len(loops), n_dma, n_reg, sorted(imm))
+    return out
