@@ -176,11 +176,13 @@ class EncoderUNetModel:
             rawT = raw.permute(1, 0, 2, 3).flip(2, 3).contiguous()
             w[name + ".dgrad"] = ops.pack_conv_weight(rawT)
             w[name + ".bias"] = g(name + ".bias")
-            if raw.shape[2] == 3:           # candidates of the fp16-operand kernel (Cin % 64 == 0, Cout % 128 == 0)
-                if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
-                    self._raw[name + ".weight"] = raw
-                if rawT.shape[1] % 64 == 0 and rawT.shape[0] % 128 == 0:
-                    self._raw[name + ".dgrad"] = rawT
+            # candidates of the fp16-operand kernels (Cin % 64 == 0, Cout % 128 == 0): the 3x3 halo kernel and, since
+            # round 4, the 1x1 GEMM kernel for skip_connection / qkv / proj_out and their data gradients (the reference's
+            # fp16 classifier runs those convolutions in fp16 as well, unet.py:817-823)
+            if raw.shape[1] % 64 == 0 and raw.shape[0] % 128 == 0:
+                self._raw[name + ".weight"] = raw
+            if rawT.shape[1] % 64 == 0 and rawT.shape[0] % 128 == 0:
+                self._raw[name + ".dgrad"] = rawT
 
         for k in ("time_embed.0", "time_embed.2"):
             w[k + ".weight"], w[k + ".bias"] = g(k + ".weight"), g(k + ".bias")
@@ -256,7 +258,8 @@ class EncoderUNetModel:
                            bias=w[n + ".in_layers.2.bias"], emit_stats=True,
                            weight_f16=self._w16(n + ".in_layers.2.weight"))
             xs = x.t if cin == cout else ops.conv2d(x, w[n + ".skip_connection.weight"], cout, 1,
-                                                    bias=w[n + ".skip_connection.bias"])
+                                                    bias=w[n + ".skip_connection.bias"],
+                                                    weight_f16=self._w16(n + ".skip_connection.weight"))
         gn2 = self._gn(h, n + ".out_layers.0", film=film_all[:, self._film_off[n]:], keep=k2)
         out = ops.conv2d(h, w[n + ".out_layers.3.weight"], cout, 3, gn=gn2, gn_silu=True,
                          bias=w[n + ".out_layers.3.bias"], res=xs, emit_stats=True,
@@ -272,7 +275,8 @@ class EncoderUNetModel:
         nh = C // hc
         k = {} if tape is not None else None
         gn = self._gn(x, n + ".norm", keep=k)
-        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"])
+        qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"],
+                         weight_f16=self._w16(n + ".qkv.weight"))
         flat = qkv.view(-1)
         S = torch.empty(B * nh, T, T, dtype=torch.float32, device=qkv.device)
         ops.bgemm(flat, flat[hc:], S, T, T, hc, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B * nh, inner=nh,
@@ -281,7 +285,8 @@ class EncoderUNetModel:
         o = torch.empty(B, H, W, C, dtype=torch.float32, device=qkv.device)
         ops.bgemm(S, flat[2 * hc:], o, T, hc, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B * nh, inner=nh,
                   sA=(nh * T * T, T * T), sB=(T * 3 * C, 3 * hc), sC=(T * C, hc))
-        out = ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True)
+        out = ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True,
+                         weight_f16=self._w16(n + ".proj_out.weight"))
         if tape is not None:
             tape.append(("attn", n, x.t, qkv, S, k))
         return out
@@ -358,7 +363,8 @@ class EncoderUNetModel:
         da1 = ops.conv2d(dh1, w[n + ".in_layers.2.dgrad"], cin, 3, weight_f16=self._w16(n + ".in_layers.2.dgrad"))
         if mode == "down":
             return self._gn_bwd(x, da1, k1, True, add=dout, dA_ups=True, add_ups=True)
-        skip = dout if cin == cout else ops.conv2d(dout, w[n + ".skip_connection.dgrad"], cin, 1)
+        skip = dout if cin == cout else ops.conv2d(dout, w[n + ".skip_connection.dgrad"], cin, 1,
+                                                   weight_f16=self._w16(n + ".skip_connection.dgrad"))
         return self._gn_bwd(x, da1, k1, True, add=skip)
 
     def _attn_bwd(self, rec, dout):
@@ -367,7 +373,7 @@ class EncoderUNetModel:
         B, H, W, C = x.shape
         T, hc = H * W, self.head_ch
         nh = C // hc
-        dO = ops.conv2d(dout, w[n + ".proj_out.dgrad"], C, 1).view(-1)
+        dO = ops.conv2d(dout, w[n + ".proj_out.dgrad"], C, 1, weight_f16=self._w16(n + ".proj_out.dgrad")).view(-1)
         flat = qkv.view(-1)
         dqkv = torch.empty_like(qkv)
         dflat = dqkv.view(-1)
@@ -386,7 +392,7 @@ class EncoderUNetModel:
                   sA=sp, sB=sq, sC=sq)
         ops.bgemm(dP, flat, dflat[hc:], T, hc, T, lda=T, ldb=3 * C, ldc=3 * C, transb=False, transa=True, batch=B * nh,
                   inner=nh, sA=sp, sB=sq, sC=sq)
-        dn = ops.conv2d(dqkv, w[n + ".qkv.dgrad"], C, 1)
+        dn = ops.conv2d(dqkv, w[n + ".qkv.dgrad"], C, 1, weight_f16=self._w16(n + ".qkv.dgrad"))
         return self._gn_bwd(x, dn, k, False, add=dout)
 
     def log_prob_grad(self, x, timesteps, y):

@@ -6,7 +6,7 @@
 #   the headline bench line (with the c3 / c4 / c5 workloads); summaries land in gpurun_out/ and the PMC json files are
 #   installed into profiles/ before the bench line is taken (bench.py binds them by source digest).
 # Every step runs under its own `timeout`: a faulting GPU once left rocprofv3 hanging for the whole remaining budget.
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 set +e
 python - <<'PY' || { echo 'GPU sanity check failed: not running the checkpoint on this box'; exit 3; }
 import torch
@@ -30,16 +30,23 @@ for k in mfma fetch write; do
   case $k in mfma) C="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE";; fetch) C="FETCH_SIZE";; write) C="WRITE_SIZE";; esac
   timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc_c2/pmc_$k -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc_c2_$k.log 2>&1
   timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc16/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16_$k.log 2>&1
+  # the same at B = 8 (the batch the class-conditional workload c5 runs): its own PMC file, bench.py picks it by batch
+  ADM_B=8 timeout -k 10 420 rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc16b8/pmc_$k -o p --output-format csv -- python /root/repo/tools/adm_fwd.py 2 > /root/repo/gpurun_out/pmc16b8_$k.log 2>&1
 done
+ADM_B=8 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $RAW/prof_adm16b8 -o adm -- python /root/repo/tools/adm_fwd.py 3 > /root/repo/gpurun_out/prof_adm16b8.log 2>&1
 cd /root/repo
 BDB=$(find $RAW/prof_bench -name "*.db" | head -1); ADB=$(find $RAW/prof_adm16 -name "*.db" | head -1)
 python tools/prof_summary.py $BDB gpurun_out/${R}_bench_kernel_stats.md > /dev/null; head -12 gpurun_out/${R}_bench_kernel_stats.md
 python tools/prof_summary.py $ADB gpurun_out/${R}_adm_fp16_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_adm_fp16_forward_kernel_stats.md
 python tools/prof_summary.py $(find $RAW/prof_c2fwd -name "*.db" | head -1) gpurun_out/${R}_celeba_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_celeba_forward_kernel_stats.md
 python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
-# dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., false, true)
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+# dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., SRC16 = false,
+# SPLIT = true, ASCALE = either: the instance with the operand-range guard runs the launches that read a raw operand)
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
+B8DB=$(find $RAW/prof_adm16b8 -name "*.db" | head -1)
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=8 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16b8 gpurun_out/${R}_adm_pmc_conv16_b8.json gpurun_out/${R}_adm_pmc_conv16_b8.md $B8DB | tail -4
+cp gpurun_out/${R}_adm_pmc_conv16_b8.json gpurun_out/${R}_adm_pmc_conv16_b8.md profiles/
 # bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
 # (profiles/*_pmc_dominant_kernel.json, profiles/*_adm_pmc_conv16.json): install this run's summaries first
 cp gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md profiles/
