@@ -12,6 +12,22 @@ struct ConvArgs {
     float* ws;          // split-K slabs [ksplit][B*Ho*Wo][Cout]
 };
 
+// The kernels address the output / residual / split-K slabs with 32-bit ELEMENT offsets and the operands (sources, packed
+// weights) through raw buffer descriptors with 32-bit BYTE sizes: every tensor of a launch must stay below 2^31 elements
+// (output side) resp. 2 GiB (operand side; the out-of-range sentinel 0x80000000 fetches the zero padding).  Larger
+// launches are refused (split the batch on the host) instead of wrapping around silently.
+static inline bool conv_sizes_addressable(const ddnm_conv_desc* d) {
+    const int64_t lim = (int64_t)1 << 31;
+    const int64_t out_el = (int64_t)d->B * d->Ho * d->Wo * d->Cout;
+    const int64_t hs = d->ups ? d->Hin / 2 : d->Hin, ws = d->ups ? d->Win / 2 : d->Win;
+    const int64_t cmax = d->C0 > d->C1 ? d->C0 : d->C1;
+    const int64_t src_b = (int64_t)d->B * hs * ws * cmax * (d->src_f16 ? 2 : 4);
+    const int64_t cout_pad = ((int64_t)d->Cout + 127) / 128 * 128;
+    const int64_t w_b = cout_pad * d->ksize * d->ksize * ((int64_t)d->C0 + d->C1) * 4;      // fp32 / split packing; fp16 is half
+    const int64_t sk_el = (int64_t)d->B * d->Ho * d->Wo * (d->SC0 > d->SC1 ? d->SC0 : d->SC1);
+    return out_el < lim && src_b < lim && w_b < lim && sk_el < lim;
+}
+
 // ---- tile geometry helper: local row r of M-tile -> output pixel
 struct TileMap {
     int img, ty0, tx0, th_unused, TW, TW_log2, flat_base, Wo;

@@ -261,6 +261,7 @@ extern "C" int ddnm_conv_gather_s16_stats_tiles(const ddnm_conv_desc* d) {
 extern "C" int ddnm_conv_gather_s16_f32(const ddnm_conv_desc* d, void* stream) {
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
+    if (!conv_sizes_addressable(d)) return DDNM_E_SHAPE;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (!(d->acc_scale > 0.f)) return DDNM_E_BADARG;

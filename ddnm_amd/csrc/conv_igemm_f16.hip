@@ -508,6 +508,7 @@ static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     // raw operands (no GroupNorm in front of the main operand, or a fused shortcut) need the operand bound: fp16 range
     if (split && !d->amax_in && (!d->gn_scale || d->skip0) && !s16_unguarded_ok()) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
+    if (!conv_sizes_addressable(d)) return DDNM_E_SHAPE;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (d->src_f16 && d->gn_scale) return DDNM_E_BADARG;

@@ -492,6 +492,7 @@ static void launch_conv(bool halo, dim3 grid, hipStream_t s, const ConvArgs& p) 
 extern "C" int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream) {
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
+    if (!conv_sizes_addressable(d)) return DDNM_E_SHAPE;
     if (d->C0 <= 0 || d->C0 % KC || d->C1 % KC || (d->C1 > 0 && !d->src1)) return DDNM_E_SHAPE;
     if ((d->ksize != 1 && d->ksize != 3) || (d->stride != 1 && d->stride != 2)) return DDNM_E_SHAPE;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;

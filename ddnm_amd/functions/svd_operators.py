@@ -699,13 +699,65 @@ def mask_color_sr(channels, img_dim, mask, scale, device):
 
 
 class GeneralA(A_functions):
-    """svd_operators.py:173-208: an explicit dense A with a full LAPACK SVD, used by none of the `--deg` choices of
-    guided_diffusion/diffusion.py:451-523.  Not rebuilt: a dense d x d operator at 3 x 256 x 256 is 1.5 TB."""
+    """svd_operators.py:173-208: an explicit dense measurement matrix A [m, d] with a full LAPACK SVD (torch.svd on the
+    host, like the reference's constructor; singular values below 1e-3 are zeroed, :184-185).  Used by none of the `--deg`
+    choices of guided_diffusion/diffusion.py:451-523 -- a dense operator at 3 x 256 x 256 would be 1.5 TB -- but it is the
+    reference's way to plug in ANY small linear degradation, so the drop-in offers it: U / Ut / V / Vt are dense
+    products on the MFMA GEMM kernel (ddnm_bgemm_f32), A / A_pinv their compositions (:52-58,68-80), At / A_pinv_eta
+    come from the base class.  Like the reference it has no Lambda / Lambda_noise (DDNM+ raises NotImplementedError)."""
+    ZERO = 1e-3
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("GeneralA (functions/svd_operators.py:173-208, dense matrix + torch.svd) is not part of "
-                                  "the DDNM sampling path; wrap the matrix in an object with A / A_pinv and pass it to "
-                                  "ddnm_diffusion as a foreign operator")
+    def __init__(self, A):
+        A = A.detach().float()
+        dev = A.device if A.is_cuda else torch.device("cuda")
+        U, S, V = torch.svd(A.cpu(), some=False)
+        S = S.clone()
+        S[S < self.ZERO] = 0
+        self._U, self._V = U.contiguous().to(dev), V.contiguous().to(dev)
+        self._Ut, self._Vt = U.t().contiguous().to(dev), V.t().contiguous().to(dev)
+        self._singulars = S.to(dev)
+        self.device = dev
+        self._m, self._d = A.shape
+        sinv = torch.where(S > 0, 1.0 / S, torch.zeros_like(S))        # host arithmetic, once
+        self._sinv_pad = _pad_scale(sinv.to(dev), self._d)
+
+    def _spectral_dim(self):
+        return self._d
+
+    @staticmethod
+    def _mat_by_vec(M, vec):            # out[b] = M @ vec[b]   (svd_operators.py:174-179)
+        v = _flat(vec)
+        rows, cols = M.shape
+        if v.shape[1] != cols:
+            raise ValueError(f"GeneralA: a vector of {v.shape[1]} entries does not fit a {rows} x {cols} factor")
+        out = torch.empty(v.shape[0], rows, dtype=torch.float32, device=v.device)
+        ops.bgemm(v, M, out, v.shape[0], rows, cols, lda=cols, ldb=cols, ldc=rows, transb=True)
+        return out
+
+    def V(self, vec):
+        return self._mat_by_vec(self._V, vec)
+
+    def Vt(self, vec):
+        return self._mat_by_vec(self._Vt, vec)
+
+    def U(self, vec):
+        return self._mat_by_vec(self._U, vec)
+
+    def Ut(self, vec):
+        return self._mat_by_vec(self._Ut, vec)
+
+    def singulars(self):
+        return self._singulars
+
+    def add_zeros(self, vec):
+        return _gather(vec, None, self._d)
+
+    def A(self, vec):                   # U . (S .* (V^T x)[:m])   (:52-58)
+        s = self._singulars.contiguous()
+        return self.U(_gather(self.Vt(vec), None, s.numel(), scale=s))
+
+    def A_pinv(self, vec):              # V . pad(S^+ .* (U^T y))   (:68-80)
+        return self.V(_gather(self.Ut(vec), None, self._d, scale=self._sinv_pad))
 
 
 class SRConv(A_functions):

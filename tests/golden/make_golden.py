@@ -387,6 +387,23 @@ def make_spectral_sr16():
     np.savez_compressed(os.path.join(HERE, "spectral_sr16.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
 
 
+def make_general_a():
+    """GeneralA (functions/svd_operators.py:173-208) of the reference on a seeded dense 64 x 192 matrix (3 x 8 x 8 image, rank
+    deficient on purpose: the singular-value threshold 1e-3 of :184-185 must act): tests/golden/general_a.npz holds the
+    basis-independent products A, A_pinv, At, A_pinv_eta and the thresholded singular values."""
+    ns = ref_import.load()
+    g = torch.Generator().manual_seed(cases.SEED + 41)
+    A = torch.randn(64, 192, generator=g) / 192 ** 0.5
+    A[40:] = A[:24] * 0.5 + 1e-5 * torch.randn(24, 192, generator=g)          # 24 nearly dependent rows -> tiny singular values
+    op = ns.svd_operators.GeneralA(A.clone())
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    w = torch.randn(4, 64, generator=g)
+    out = dict(A_mat=A.numpy(), x=x.numpy(), w=w.numpy(), singulars=op.singulars().numpy(), A=op.A(x.clone()).numpy(),
+               A_pinv=op.A_pinv(w.clone()).numpy(), At=op.At(w.clone()).numpy(),
+               A_pinv_eta=op.A_pinv_eta(w.clone(), 0.3).numpy())
+    np.savez_compressed(os.path.join(HERE, "general_a.npz"), **{k: v.astype(np.float32) for k, v in out.items()})
+
+
 def make_full(names):
     """--full-adm / --full-c2b8: the FULL BASELINE configurations through the real reference loop
     (functions/svd_ddnm.py:19-78), operators built as guided_diffusion/diffusion.py:451-523 builds them, fp32
@@ -475,6 +492,7 @@ def main():
     ap.add_argument("--classifier-only", action="store_true", help="only (re)generate the classifier goldens")
     ap.add_argument("--spectral-only", action="store_true", help="only (re)generate the V / Vt / U / Ut / At goldens")
     ap.add_argument("--spectral-sr16-only", action="store_true", help="only (re)generate the ratio-16 SuperResolution goldens")
+    ap.add_argument("--general-a-only", action="store_true", help="only (re)generate the GeneralA goldens")
     args = ap.parse_args()
     if args.full_cases:
         return make_full(args.full_cases.split(","))
@@ -482,6 +500,8 @@ def main():
         return make_spectral()
     if args.spectral_sr16_only:
         return make_spectral_sr16()
+    if args.general_a_only:
+        return make_general_a()
     if args.classifier_only:
         return make_classifier()
     if args.plus_deblur_only:

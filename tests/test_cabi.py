@@ -135,3 +135,17 @@ def test_conv16_plans_without_a_gpu(lib):
     assert plan(4, 8, 1024, 1024, 3)[0] is False                    # 8x8 images have no 3x3 pixel tile (im2col route)
     assert plan(4, 256, 256, 6, 3, out_nchw_f32=1)[:2] == (True, 0)    # the fp32 NCHW output convolution
     assert plan(4, 256, 200, 256, 3)[0] is False                    # Cin must be a multiple of 64
+
+
+def test_conv_entry_points_refuse_tensors_beyond_32bit_offsets(lib):
+    """The convolution kernels address outputs with 32-bit element offsets and operands through 32-bit buffer descriptors:
+    a launch whose tensors exceed that must be refused (DDNM_E_SHAPE), not wrap around (checked before any launch, so
+    this runs without a GPU)."""
+    from ddnm_amd._lib import ConvDesc
+    for fn in (lib.ddnm_conv2d_f32, lib.ddnm_conv3x3_s16_f32, lib.ddnm_conv3x3_f16_f32, lib.ddnm_conv_gather_s16_f32,
+               lib.ddnm_conv1x1_f16_f32):
+        d = ConvDesc()
+        d.src0 = d.weight = d.out = d.gn_scale = d.gn_shift = 4096         # non-null dummies: never dereferenced
+        d.B, d.Hin, d.Win, d.C0, d.Cout, d.ksize, d.stride, d.pad, d.Ho, d.Wo = 256, 256, 256, 128, 128, 3, 1, 1, 256, 256
+        d.acc_scale = 1.0
+        assert fn(ctypes.byref(d), None) == -2, fn.__name__                # 2^31 output elements exactly: refused

@@ -408,6 +408,27 @@ def test_superresolution_ratio16_surface(hip, golden_dir):
         assert rel(op.Lambda_noise(z, a, 0.4, st, 0.85, e), g[f"Lambda_noise_{tag}"]) < 1e-5
 
 
+def test_general_a_dense_operator(hip, golden_dir):
+    """GeneralA (functions/svd_operators.py:173-208): a dense measurement matrix with a full host SVD; every product is a
+    ddnm_bgemm_f32 launch.  Basis-independent outputs against the reference class (tests/golden/general_a.npz: rank-deficient
+    matrix, so the 1e-3 singular-value threshold acts), the SVD algebra, and a DDNM run with it as the operator."""
+    from ddnm_amd.functions.svd_operators import GeneralA
+    g = {k: torch.from_numpy(v) for k, v in np.load(f"{golden_dir}/general_a.npz").items()}
+    op = GeneralA(g["A_mat"].cuda())
+    x, w = g["x"].cuda(), g["w"].cuda()
+    assert torch.equal((op.singulars() == 0).cpu(), g["singulars"] == 0)
+    assert rel(op.singulars(), g["singulars"]) < 1e-6
+    assert rel(op.A(x), g["A"]) < 2e-5 and rel(op.A_pinv(w), g["A_pinv"]) < 2e-5
+    assert rel(op.At(w), g["At"]) < 2e-5 and rel(op.A_pinv_eta(w, 0.3), g["A_pinv_eta"]) < 2e-5
+    xf = x.reshape(4, -1)
+    assert rel(op.V(op.Vt(x)), xf) < 2e-6 and rel(op.U(op.Ut(w)), w) < 2e-6
+    assert rel(op.A(op.A_pinv(op.A(x))), op.A(x)) < 2e-5            # A A^+ A = A
+    z = op.add_zeros(w)
+    assert z.shape == (4, 192) and torch.equal(z[:, :64], w) and not bool(z[:, 64:].any())
+    with pytest.raises(NotImplementedError):                        # like the reference: no Lambda (svd_operators.py:93-97)
+        op.Lambda(xf, 0.9, 0.2, 0.3, 0.85)
+
+
 @pytest.mark.parametrize("B,C,H,gn", [(2, 128, 64, True), (1, 64, 32, False), (3, 128, 32, True)])
 def test_small_cout_output_conv(hip, B, C, H, gn):
     """conv_out of the celeba Model (128 -> 3, GroupNorm + swish fused, NCHW result) on the vector-ALU kernel."""
