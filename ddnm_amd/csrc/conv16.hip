@@ -33,6 +33,7 @@ struct Conv16Args {
     int m_tiles, n_tiles, ksplit, M;           // M = B*H*W output pixels
     int Hs, Ws;                                // source resolution (H/2 when ups)
     int wmajor;                                // workgroup order inside a slice: 1 = pixel tiles fastest (weight-heavy launch)
+    int slab16;                                // split-K partial slabs in fp16 (see the epilogue) instead of fp32
 };
 
 #ifndef DDNM_P16_EARLY_RES
@@ -439,8 +440,16 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     // residual tile of the epilogue: requested NOW, before the barrier and the LDS transposition, so that its HBM
     // latency overlaps them (nothing else hides it with one workgroup per CU)
     constexpr int ITS = MT * 32 / 8;                 // lane -> (pixel = it*8 + lane/8, 8 channels = piece lane%8)
-    const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
-    _Float16* const out = reinterpret_cast<_Float16*>(d.out);
+    // Split-K launches with fp16 slabs (`slab16`) write their partial tile through the SAME LDS transposition as a
+    // finished tile -- 16-byte stores, 8 lanes = one 128-byte line, half the bytes of an fp32 slab -- into slab `slice`;
+    // bias / residual / statistics belong to the reduction pass.  (The fp32 form stores f32x4 per lane and pixel: 32-byte
+    // segments.)  A partial sum rounded to fp16 carries 2^-12 of ITS OWN magnitude, the same order as the final rounding
+    // of the fp16 output tensor, so the result's error grows by about sqrt(2) (full-configuration goldens: tests).
+    const bool partial16 = p.ksplit > 1 && p.slab16 != 0;
+    const _Float16* const res = partial16 ? nullptr : reinterpret_cast<const _Float16*>(d.res);
+    _Float16* const out = partial16 ? reinterpret_cast<_Float16*>(d.workspace) + (size_t)slice * p.M * d.Cout
+                                    : reinterpret_cast<_Float16*>(d.out);
+    const float* const bias = partial16 ? nullptr : d.bias;
     const int cbase = n_tile * C16_BN + wn * 64;
     const bool wave_on = cbase < d.Cout;            // Cout % 64 == 0: a wave's 64-channel slice is all in or all out
     const int chn = cbase + lpiece * 8;
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         }
         return;
     }
-    if (p.ksplit > 1) {
+    if (p.ksplit > 1 && !partial16) {
         float* ws = d.workspace + (size_t)slice * p.M * d.Cout;
         if (!wave_on) return;
 #pragma unroll
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int ch = cbase + j * 32 + 8 * rg + 4 * kh;
-                bias4[rg] = d.bias ? *reinterpret_cast<const f32x4*>(d.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                bias4[rg] = bias ? *reinterpret_cast<const f32x4*>(bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             }
         }
     }
-    if (d.stats_out) {
+    if (d.stats_out && !partial16) {
         // GroupNorm partials of the tensor just written (of the ROUNDED values the consumer will read):
         // reduce over the 8 pixel rows of a wave (lanes with equal lane%8), then over the two pixel-halves (wm)
 #pragma unroll
@@ -613,6 +622,18 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 // grid (B * tpi, ceil(Cout / 1024)); one workgroup per (image, pixel tile, 1024-channel slab); a thread owns one
 // float4 channel column and walks the tile's pixels (fixed order, no atomics).
 // =====================================================================================
+// one float4 channel column of slab `k` at element offset `o` (fp32 slabs, or the fp16 slabs of `slab16` launches)
+template <bool SLAB16>
+__device__ __forceinline__ f32x4 slab_load4(const float* __restrict__ ws, size_t o) {
+    if constexpr (SLAB16) {
+        const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const _Float16*>(ws) + o);
+        return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    } else {
+        return *reinterpret_cast<const f32x4*>(ws + o);
+    }
+}
+
+template <bool SLAB16>
 static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const Conv16Args p, int tpi) {
     __shared__ f32x4 red[2][256];
     const ddnm_conv16_desc& d = p.d;
@@ -635,9 +656,9 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const 
             const int p2 = t * P + pp;
             const size_t o = ((size_t)b * hw + p2) * d.Cout + n;
             // all slices' loads are independent: issue them back to back (the slab sum is the latency chain here)
-            f32x4 v = *reinterpret_cast<const f32x4*>(d.workspace + o);
+            f32x4 v = slab_load4<SLAB16>(d.workspace, o);
 #pragma unroll 4
-            for (int k = 1; k < p.ksplit; ++k) v = v + *reinterpret_cast<const f32x4*>(d.workspace + o + k * slab);
+            for (int k = 1; k < p.ksplit; ++k) v = v + slab_load4<SLAB16>(d.workspace, o + k * slab);
             v = v + add;
             if (res) {
                 size_t ro = o;
@@ -676,6 +697,7 @@ static __global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const 
 // fixed order (no atomics: repeated launches are bit-identical).
 // =====================================================================================
 constexpr int C16_FIN_THREADS = 1024;
+template <bool SLAB16>
 static __global__ __launch_bounds__(C16_FIN_THREADS) void conv16_splitk_reduce_fin_kernel(const Conv16Args p, int CS) {
     __shared__ f32x4 red[2][C16_FIN_THREADS];
     __shared__ double chan[2][64];
@@ -716,11 +738,11 @@ static __global__ __launch_bounds__(C16_FIN_THREADS) void conv16_splitk_reduce_f
             const int pp = p0 + u * rows;
             ok[u] = pp < hw;
             o[u] = ((size_t)b * hw + (ok[u] ? pp : 0)) * d.Cout + n;
-            v[u] = *reinterpret_cast<const f32x4*>(wsp + o[u]);
+            v[u] = slab_load4<SLAB16>(wsp, o[u]);
         }
         for (int k = 1; k < p.ksplit; ++k) {
 #pragma unroll
-            for (int u = 0; u < PB; ++u) v[u] = v[u] + *reinterpret_cast<const f32x4*>(wsp + o[u] + k * slab);
+            for (int u = 0; u < PB; ++u) v[u] = v[u] + slab_load4<SLAB16>(wsp, o[u] + k * slab);
         }
         if (res) {
 #pragma unroll
@@ -798,6 +820,13 @@ static __global__ __launch_bounds__(C16_FIN_THREADS) void conv16_splitk_reduce_f
         d.fin_scale[(size_t)b * d.Cout + cb + tid] = sc;
         d.fin_shift[(size_t)b * d.Cout + cb + tid] = sh;
     }
+}
+
+// fp16 split-K slabs (default); DDNM_P16_SLAB32=1 keeps the fp32 slabs of rounds 2-3 (A/B switch).  The workspace the
+// host provides is sized for fp32 slabs either way (ddnm_conv16_workspace_floats).
+static bool slab16_enabled() {
+    static const bool on = [] { const char* e = getenv("DDNM_P16_SLAB32"); return !(e && e[0] == '1'); }();
+    return on;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -986,6 +1015,7 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     // weight bytes > activation bytes, and few enough pixel tiles per weight stream that one XCD's CUs do not all pull
     // the same weight lines at the same moment (32 sharers measured SLOWER than replicating the weights over XCDs)
     p.wmajor = ((long)d->Cout * pl.taps > (long)p.M && pl.m_tiles <= DDNM_P16_WMAJOR_MAXM) ? 1 : 0;
+    p.slab16 = slab16_enabled() ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pl.m_tiles * pl.n_tiles * pl.ksplit);
     if (pl.small) {
@@ -999,10 +1029,14 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
         else { DDNM_LAUNCH((conv16_kernel<1, 1, 4>), grid, dim3(512), 0, s, p); }
     }
     if (pl.fin_cs > 0) {
-        DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel, dim3(d->B, d->Cout / pl.fin_cs), dim3(C16_FIN_THREADS), 0, s, p, pl.fin_cs);
+        const dim3 g(d->B, d->Cout / pl.fin_cs);
+        if (p.slab16) { DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel<true>, g, dim3(C16_FIN_THREADS), 0, s, p, pl.fin_cs); }
+        else { DDNM_LAUNCH(conv16_splitk_reduce_fin_kernel<false>, g, dim3(C16_FIN_THREADS), 0, s, p, pl.fin_cs); }
     } else if (pl.ksplit > 1) {
         const int tpi = pl.stats_tiles;
-        DDNM_LAUNCH(conv16_splitk_reduce_kernel, dim3(d->B * tpi, (d->Cout + 255) / 256), dim3(256), 0, s, p, tpi);
+        const dim3 g(d->B * tpi, (d->Cout + 255) / 256);
+        if (p.slab16) { DDNM_LAUNCH(conv16_splitk_reduce_kernel<true>, g, dim3(256), 0, s, p, tpi); }
+        else { DDNM_LAUNCH(conv16_splitk_reduce_kernel<false>, g, dim3(256), 0, s, p, tpi); }
     }
     return 0;
 }
