@@ -90,12 +90,10 @@ _NO_FUSED_GN = _os.environ.get("DDNM_NO_FUSED_GN") == "1"      # A/B switch for 
 class Act:
     """An NHWC activation plus, when its producer could emit them, the GroupNorm partials of it
     (per-(M tile, channel) sum / sum of squares written by the convolution epilogue)."""
-    __slots__ = ("t", "stats", "tiles", "gn", "amax")
+    __slots__ = ("t", "stats", "tiles", "gn")
 
-    def __init__(self, t, stats=None, tiles=0, gn=None, amax=None):
+    def __init__(self, t, stats=None, tiles=0, gn=None):
         self.t, self.stats, self.tiles = t, stats, tiles
-        # [B][AMAX_N] fp32 upper bounds of |t| per image (operand-range guard of the split-fp16 kernels, see amax_bound)
-        self.amax = amax
         # (scale, shift, name): the affine of the consumer GroupNorm `name`, already finalized by the producing launch
         # (split-K reduction pass, ddnm_conv16_desc::fin_*); valid until the next finalize reuses the workspace
         self.gn = gn
