@@ -86,11 +86,13 @@ class Model:
             blocks, attns = [], []
             for ib in range(nrb):
                 rb = _ResBlock(f"down.{lvl}.block.{ib}", block_in, block_out)
+                rb.res = res
                 blocks.append(rb)
                 self.res_blocks.append(rb)
                 block_in = block_out
                 if res in self.attn_resolutions:
                     attns.append(_Attn(f"down.{lvl}.attn.{ib}", block_in))
+                    attns[-1].res = res
                 chans.append(block_in)
             has_down = lvl != self.num_resolutions - 1
             if has_down:
@@ -99,6 +101,8 @@ class Model:
             self.down.append((blocks, attns, has_down, block_in))
         self.mid = [_ResBlock("mid.block_1", block_in, block_in), _Attn("mid.attn_1", block_in),
                     _ResBlock("mid.block_2", block_in, block_in)]
+        for m in self.mid:
+            m.res = res
         self.res_blocks += [self.mid[0], self.mid[2]]
         self.up = {}
         for lvl in reversed(range(self.num_resolutions)):
@@ -108,11 +112,13 @@ class Model:
                 skip = chans.pop()
                 rb = _ResBlock(f"up.{lvl}.block.{ib}", block_in + skip, block_out)
                 rb.split = (block_in, skip)
+                rb.res = res
                 blocks.append(rb)
                 self.res_blocks.append(rb)
                 block_in = block_out
                 if res in self.attn_resolutions:
                     attns.append(_Attn(f"up.{lvl}.attn.{ib}", block_in))
+                    attns[-1].res = res
             has_up = lvl != 0
             if has_up:
                 res *= 2
@@ -281,6 +287,8 @@ class Model:
         w["norm_out.weight"], w["norm_out.bias"] = g("norm_out.weight"), g("norm_out.bias")
         w["conv_out.weight"] = ops.pack_conv_weight(g("conv_out.weight"))
         w["conv_out.bias"] = g("conv_out.bias")
+        if self.split16:
+            self._guard_normalised_operands(sd, w)
         half = self.ch // 2
         freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))   # models.py:16-17
         w["temb.freq"] = freq.to(dev)
@@ -290,6 +298,31 @@ class Model:
         if getattr(self, "_graphs", None) is not None:
             self._graphs.reset()
         return self
+
+    def _guard_normalised_operands(self, sd, w):
+        """The split-fp16 kernels scale RAW operands per launch (ops.conv2d, ddnm_conv_desc::amax_in); a GroupNorm'd
+        operand carries no run-time bound because it has a static one: |GN(x) * gamma + beta| <= sqrt(n) * max|gamma| +
+        max|beta| over the n = H*W*C/32 elements of a group (swish does not increase it).  Checked here, once per
+        checkpoint: a norm whose bound does not fit fp16 with a factor 2 to spare sends its consumer to the exact-fp32
+        kernel (its split weights are dropped).  No shipped checkpoint is expected to trip this (gamma ~ 1: bound ~ 512);
+        it makes "no operand-range limit" hold for ANY state dict."""
+        groups = 32
+        dropped = []
+
+        def bound(norm, res, channels):
+            g = sd[norm + ".weight"].detach().abs().max().item()
+            b = sd[norm + ".bias"].detach().abs().max().item()
+            return math.sqrt(res * res * max(1, channels // groups)) * g + b
+        for rb in self.res_blocks:
+            for norm, conv, ch in (("norm1", "conv1", rb.cin), ("norm2", "conv2", rb.cout)):
+                if bound(f"{rb.name}.{norm}", rb.res, ch) >= 32768.0 and w.pop(f"{rb.name}.{conv}.s16", None) is not None:
+                    dropped.append(f"{rb.name}.{conv}")
+        attns = [a for (_, at, _, _) in self.down for a in at] + [self.mid[1]] + [a for lvl in self.up for a in self.up[lvl][1]]
+        for a in attns:
+            if bound(f"{a.name}.norm", a.res, a.c) >= 32768.0 and w.pop(f"{a.name}.qkv.s16", None) is not None:
+                dropped.append(f"{a.name}.qkv")
+        self.s16_dropped = dropped
+        return dropped
 
     # ------------------------------------------------------------------ forward
     def _workspace(self, B):

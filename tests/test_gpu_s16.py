@@ -342,3 +342,26 @@ def test_gather_split_kernel_vs_fp64_and_fp32_kernel(case):
             assert ((st[..., 1] - s2).abs().max() / s2.abs().max()).item() < 2e-6
     assert errs[True] < 8e-7, errs
     assert errs[True] <= 1.25 * errs[False] + 2e-8, errs
+
+
+def test_normalised_operand_bound_is_checked_at_load_time():
+    """GroupNorm'd operands carry no run-time bound because they have a static one (sqrt(n) * max|gamma| + max|beta|); a
+    checkpoint whose bound does not fit fp16 sends that convolution to the exact-fp32 kernel at load_state_dict time."""
+    from oracle import cases
+    from ddnm_amd.guided_diffusion.models import Model
+    cfg = cases.weights.celeba_config(resolution=64, ch=128, ch_mult=(1, 2, 2), attn_resolutions=(16,))
+    a, b = Model(cfg, device=DEV, split16=True), Model(cfg, device=DEV, split16=False)
+    sd = a.random_state_dict(seed=7)
+    a.load_state_dict(sd)
+    assert a.s16_dropped == []                                  # gamma ~ 1: nothing is dropped
+    sd = dict(sd)
+    sd["down.0.block.0.norm2.weight"] = sd["down.0.block.0.norm2.weight"] * 3000.0      # bound = sqrt(64*64*4) * 3300 = 4e5
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    assert a.s16_dropped == ["down.0.block.0.conv2"]
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(2, 3, 64, 64, device=DEV, generator=g)
+    t = torch.tensor([999.0, 37.0], device=DEV)
+    ea, eb = a(x, t), b(x, t)
+    assert torch.isfinite(ea).all()
+    assert ((ea - eb).double().norm() / eb.double().norm()).item() < 3e-6
