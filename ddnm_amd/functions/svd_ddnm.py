@@ -113,14 +113,19 @@ def _side_stream(device, priority):
 
 
 class _GuidanceAhead:
-    """Classifier guidance on its own HIP stream, one reverse step ahead of the UNet.
+    """Classifier guidance on its own HIP stream, ahead of the UNet.
 
     The reference evaluates `cls_fn(x, t, classes)` on the INITIAL noise `x` (svd_ddnm.py:49-52; quirk kept), so the
-    guidance term of a step depends only on (x, t, class) -- not on x_t, i.e. not on the UNet chain.  Its ~700 launches
+    guidance term of a step depends only on (x, t, class) -- not on x_t, i.e. not on the UNet chain.  Its ~600 launches
     (classifier forward + explicit input-gradient backward, many of them latency-bound with a handful of workgroups)
-    therefore run on a second stream while the first stream runs the UNet forward of the same step; the main stream
-    waits on an event right before it combines the two.  Same kernels, same inputs, same results; only the order in
-    which two independent launch sequences reach the GPU changes.  DDNM_CLS_OVERLAP=0 restores the serial order."""
+    therefore run on a second stream while the first stream runs the UNet; the main stream waits on an event right before
+    it combines the two.  Since round 4 the guidance terms of G consecutive reverse steps (DDNM_CLS_GROUP, default 4) are
+    evaluated in one pass over the batch [x; ...; x] with the timestep vector [t_k ... t_k, t_k+1 ... t_k+1, ...] (the
+    classifier conditions per sample, so this IS the reference's computation for each of the steps): the low-resolution
+    half of the classifier is a chain of launches whose time does not depend on the batch, and one chain now serves G
+    steps.  Same inputs, same arithmetic; the launch plans of a batch of G n differ from those of n in summation order
+    only (fp32: ~1e-7).  DDNM_CLS_PAIR=0 evaluates step by step (bit-identical to the serial order), DDNM_CLS_OVERLAP=0
+    restores the serial order on the main stream."""
 
     def __init__(self, cls_fn, x, n, t_values, t_of=None, cls=None):
         import collections
@@ -129,7 +134,23 @@ class _GuidanceAhead:
         self.t_of, self.cls = t_of, cls
         self.t_values, self.pos = t_values, 0
         self.serial = os.environ.get("DDNM_CLS_OVERLAP") == "0"
+        # steps per guidance pass: DDNM_CLS_GROUP (default 4: c5 at B = 8 on one MI355X 2.92 / 3.00 / 3.03 / 3.04 images/s
+        # for 1 / 2 / 3 / 4, same box); DDNM_CLS_PAIR=0 is the step-by-step form
+        grp = int(os.environ.get("DDNM_CLS_GROUP", "4")) if os.environ.get("DDNM_CLS_PAIR", "1") != "0" else 1
+        self.group = max(1, min(grp, len(t_values))) if (not self.serial and n > 0) else 1
         self.queue = collections.deque()
+        if self.group > 1:
+            # per-run constants of the grouped evaluation, built on the main stream before the side stream forks: the
+            # replicated batch, its class vector and ONE host-to-device table of the grouped timestep vectors
+            G = self.group
+            self.xg = torch.cat([x] * G, 0)
+            rows = []
+            for i in range(0, len(t_values), G):
+                ts = list(t_values[i:i + G])
+                ts = ts + [ts[-1]] * (G - len(ts))                   # a ragged last group uses the first len(ts) * n rows only
+                rows.append([float(tv) for tv in ts for _ in range(n)])
+            self.tg = torch.tensor(rows, dtype=torch.float32).to(x.device)
+            self.clsg = torch.tensor([class_num] * (G * n), dtype=torch.long).to(x.device)
         if not self.serial:
             self.main = torch.cuda.current_stream()
             # high priority: the guidance pass is a long chain of small dependent launches (latency-bound), the UNet a
@@ -144,6 +165,18 @@ class _GuidanceAhead:
         if self.pos >= len(self.t_values):
             return
         tv = self.t_values[self.pos]
+        G = self.group
+        if G > 1:
+            g = min(G, len(self.t_values) - self.pos)            # steps served by this pass
+            m = g * self.n
+            with torch.cuda.stream(self.side):
+                gg = self.cls_fn(self.xg[:m], self.tg[self.pos // G][:m], self.clsg[:m])
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            for j in range(g):
+                self.queue.append((self.t_values[self.pos + j], gg[j * self.n:(j + 1) * self.n], ev, gg))
+            self.pos += g
+            return
         self.pos += 1
         with torch.cuda.stream(self.side):
             if self.t_of is not None:        # views of the per-run tables (built on the main stream before this one forked)
@@ -154,17 +187,20 @@ class _GuidanceAhead:
             g = self.cls_fn(self.x, t, cls)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        self.queue.append((tv, g, ev))
+        self.queue.append((tv, g, ev, g))
 
     def grad(self, tv, t, cls):
         """Gradient of the reverse step at timestep `tv` (called AFTER the UNet forward of that step was enqueued)."""
         if self.serial:
             return self.cls_fn(self.x, t, cls)
-        tq, g, ev = self.queue.popleft()
+        tq, g, ev, owner = self.queue.popleft()
         assert tq == tv, (tq, tv)
         self.main.wait_event(ev)
-        g.record_stream(self.main)                        # allocated on the side stream, consumed on the main one
-        self._launch()                                    # the next step's guidance starts under this step's tail
+        owner.record_stream(self.main)                    # allocated on the side stream, consumed on the main one
+        if len(self.queue) <= max(0, self.group - 1):
+            # the next evaluation starts under this step's tail; a grouped pass (G times the work) is launched when the
+            # FIRST term of the previous group is consumed, so it has G UNet steps to hide behind
+            self._launch()
         return g
 
     def close(self):

@@ -204,6 +204,7 @@ def test_guidance_stream_equals_serial_order(hip, monkeypatch):
     model = create_model(**vars(cfg.model))
     model.load_state_dict(sd)
     outs = {}
+    monkeypatch.setenv("DDNM_CLS_PAIR", "0")        # step-by-step evaluation: the launches of the serial order
     for mode in ("1", "0", "1"):
         monkeypatch.setenv("DDNM_CLS_OVERLAP", mode)
         xs, x0s = ddnm_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, cls_fn=make_cond_fn(clf, 2.0),
@@ -216,3 +217,14 @@ def test_guidance_stream_equals_serial_order(hip, monkeypatch):
     for u, v, w in zip(a, b, c):
         assert bool(torch.isfinite(u).all())
         assert torch.equal(u, v) and torch.equal(u, w)
+    # default mode: the guidance terms of two consecutive steps in ONE pass over [x; x] (round 4).  Same arithmetic per
+    # sample; a batch of 2n picks other split-K plans than n, i.e. another fp32 summation order
+    monkeypatch.setenv("DDNM_CLS_PAIR", "1")
+    monkeypatch.setenv("DDNM_CLS_OVERLAP", "1")
+    xs, x0s = ddnm_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, cls_fn=make_cond_fn(clf, 2.0),
+                             classes=None, config=cfg, noise=[n.cuda() for n in tape], return_cpu=False)
+    xp, _ = ddnm_plus_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, 0.1, cls_fn=make_cond_fn(clf, 2.0),
+                                classes=None, config=cfg, noise=[n.cuda() for n in tape], return_cpu=False)
+    torch.cuda.synchronize()
+    for got, want in ((xs[0], b[0]), (x0s[0], b[1]), (xp[0], b[2])):
+        assert rel(got, want) < 2e-5, rel(got, want)
