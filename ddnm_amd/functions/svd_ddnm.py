@@ -137,7 +137,9 @@ class _GuidanceAhead:
         # steps per guidance pass: DDNM_CLS_GROUP (default 4: c5 at B = 8 on one MI355X 2.92 / 3.00 / 3.03 / 3.04 images/s
         # for 1 / 2 / 3 / 4, same box); DDNM_CLS_PAIR=0 is the step-by-step form
         grp = int(os.environ.get("DDNM_CLS_GROUP", "4")) if os.environ.get("DDNM_CLS_PAIR", "1") != "0" else 1
-        self.group = max(1, min(grp, len(t_values))) if (not self.serial and n > 0) else 1
+        # ... capped so that the replicated batch stays at <= 32 images: the classifier's largest fp32 activation
+        # (128 channels at 256 x 256) must stay below the 2 GiB a convolution launch can address
+        self.group = max(1, min(grp, len(t_values), max(1, 32 // n))) if (not self.serial and n > 0) else 1
         self.queue = collections.deque()
         if self.group > 1:
             # per-run constants of the grouped evaluation, built on the main stream before the side stream forks: the
