@@ -220,12 +220,8 @@ class Model:
         w["conv_in.bias"] = g("conv_in.bias")
         if 9 * self.in_channels <= CIN_PAD:       # 3 input channels: the 27 taps fit one 32-wide K chunk
             w["conv_in.weight.im2col"] = ops.pack_conv_in_weight_im2col(g("conv_in.weight"), CIN_PAD)
-            if self.split16:
-                # the same [Cout][32] matrix in the split packing: the launch is output-store bound (268 MB at B = 8), the
-                # gather form of the split arithmetic gets there at half the time of the fp32-MFMA tile kernel
-                flat = w["conv_in.weight.im2col"][:self.ch].reshape(self.ch, CIN_PAD, 1, 1).contiguous()
-                sc = ops.s16_weight_scale(flat)
-                w["conv_in.s16.im2col"] = (ops.pack_conv_weight_s16(flat, sc), sc, None)
+            # (stays on the fp32 MFMA tile kernel: the launch is output-store bound -- 268 MB at B = 8 -- and the gather form
+            #  of the split arithmetic, with half the workgroups per CU, measured 146 us against 118 us)
         tw, tb = [], []
         for rb in self.res_blocks:
             n = rb.name
@@ -431,12 +427,8 @@ class Model:
 
         if "conv_in.weight.im2col" in w:
             # conv_in as a 1x1 convolution over the im2col'ed image: K = 32 instead of 9 x 32 zero-padded channels
-            x = x.contiguous()
-            xin = ops.nchw_im2col3x3_pad(x, CIN_PAD)
-            s16 = w.get("conv_in.s16.im2col")
-            # raw operand of a split launch: its bound is the image's (the im2col rows repeat the image's values)
-            hs = [ops.conv2d(xin, w["conv_in.weight.im2col"], self.ch, 1, bias=w["conv_in.bias"], emit_stats=True,
-                             weight_s16=s16, raw_amax=None if s16 is None else ops.amax_bound(x.float()))]
+            xin = ops.nchw_im2col3x3_pad(x.contiguous(), CIN_PAD)
+            hs = [ops.conv2d(xin, w["conv_in.weight.im2col"], self.ch, 1, bias=w["conv_in.bias"], emit_stats=True)]
         else:
             xin = ops.nchw_to_nhwc_pad(x.contiguous(), CIN_PAD)
             hs = [ops.conv2d(xin, w["conv_in.weight"], self.ch, 3, bias=w["conv_in.bias"], emit_stats=True)]
