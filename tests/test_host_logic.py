@@ -192,3 +192,19 @@ def test_bench_refuses_more_gpus_than_visible():
                        text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert "refusing to measure fewer" in r.stderr and "{" not in r.stdout
+
+
+def test_step_tables_hold_every_reverse_step_time():
+    """The per-run timestep table of the sampling loop (one host-to-device copy instead of a fill kernel per step):
+    one row per distinct reverse-step time, in the reference's float form `torch.ones(n) * i` (svd_ddnm.py:40)."""
+    from ddnm_amd.functions.svd_ddnm import _step_tables, get_schedule_jump
+    times = get_schedule_jump(20, 2, 2)
+    t_of, cls = _step_tables(times, 50, 3, "cpu", True)
+    seen = set()
+    for a, c in zip(times[:-1], times[1:]):
+        if c < a:
+            t = t_of(a * 50)
+            assert t.shape == (3,) and t.dtype == torch.float32 and bool((t == float(a * 50)).all())
+            seen.add(a * 50)
+    assert len(seen) == 20 and cls.tolist() == [951, 951, 951] and cls.dtype == torch.long
+    assert _step_tables(times, 50, 3, "cpu", False)[1] is None
