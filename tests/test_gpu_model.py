@@ -69,3 +69,26 @@ def test_model_requires_weights_and_gpu(hip):
     cfg, _ = cases.celeba_net("small")
     with pytest.raises(RuntimeError):
         Model(cfg)(torch.zeros(1, 3, 32, 32, device="cuda"), torch.zeros(1, device="cuda"))
+
+
+def test_celeba_model_graph_replay_equals_eager(hip):
+    """`Model.enable_graphs()` (hipGraph replay, ddnm_amd/graph.py) on the split-fp16 engine: the operand-bound tensors of
+    the range guard (ops.amax_bound, the finalize launch's amax output) are allocated inside the capture like every other
+    intermediate, so a replay on new inputs must equal the eager forward bit for bit."""
+    import torch
+    from oracle import cases
+    from ddnm_amd.guided_diffusion.models import Model
+    cfg = cases.weights.celeba_config(resolution=64, ch=128, ch_mult=(1, 2, 2), attn_resolutions=(16,))
+    m = Model(cfg, device="cuda")
+    m.load_state_dict(m.random_state_dict(seed=3))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn(2, 3, 64, 64, device="cuda", generator=g) * s for s in (1.0, 40.0)]
+    ts = [torch.tensor([500.0, 20.0], device="cuda"), torch.tensor([990.0, 0.0], device="cuda")]
+    eager = [m(x, t).clone() for x, t in zip(xs, ts)]
+    m.enable_graphs()
+    for _ in range(2):
+        for x, t, e in zip(xs, ts, eager):
+            out = m(x, t)
+            torch.cuda.synchronize()
+            assert torch.equal(out, e)
+    m.disable_graphs()
