@@ -144,6 +144,15 @@ PROTOTYPES = {
                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
                                   c_void_p]),
     "ddnm_gn_bwd_nchunk": (c_int32, [c_int32, c_int32]),
+    "ddnm_gn_bwd_h16": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32,
+                                  c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p,
+                                  c_void_p]),
+    "ddnm_pool_tokens_h16": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                       c_void_p]),
+    "ddnm_pool_tokens_bwd_h16": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_attn16_d64_lse": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "ddnm_attn16_d64_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_int32, c_void_p]),
     "ddnm_softmax_bwd_rows_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "ddnm_pool_tokens_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                        c_void_p]),
@@ -208,7 +217,7 @@ class DDNMHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def lib():

@@ -24,7 +24,7 @@ constexpr int AT_D = 64, AT_KT = 64;           // head dim, keys per tile
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out,
-                                                             int T, int C, float scale_log2) {
+                                                             float* __restrict__ lse, int T, int C, float scale_log2) {
     constexpr int NT = NW * 64;
     constexpr int PIECES = AT_KT * 8;                 // 16-byte pieces per 64 x 64 fp16 tile
     constexpr int PPT = PIECES / NT;                  // pieces per thread per tile (2 for 4 waves, 4 for 2)
@@ -160,6 +160,9 @@ __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __r
     }
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
+    // base-2 log-sum-exp of the query's scaled logits: the backward pass (attn16_bwd.hip) recomputes the probabilities
+    // as exp2(s * scale_log2 - lse) instead of reading a [T][T] tensor
+    if (lse && kh == 0) lse[((size_t)b * gridDim.y + head) * T + q0 + ql] = m + __log2f(l);
     _Float16* op = out + ((size_t)b * T + q0 + ql) * C + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(NW * 64) void attn16_d64_kernel(const _Float16* __r
         }
 }
 
-extern "C" int ddnm_attn16_d64(const void* qkv, void* out, int32_t B, int32_t T, int32_t C, void* stream) {
+extern "C" int ddnm_attn16_d64_lse(const void* qkv, void* out, float* lse, int32_t B, int32_t T, int32_t C, void* stream) {
     if (!qkv || !out || B <= 0 || T <= 0 || C <= 0) return DDNM_E_BADARG;
     if (C % 64 || T % 64) return DDNM_E_SHAPE;
     const int nh = C / 64;
@@ -180,10 +183,14 @@ extern "C" int ddnm_attn16_d64(const void* qkv, void* out, int32_t B, int32_t T,
     hipStream_t s = (hipStream_t)stream;
     if (T % 128 == 0) {
         DDNM_LAUNCH((attn16_d64_kernel<4>), dim3(T / 128, nh, B), dim3(256), 0, s, reinterpret_cast<const _Float16*>(qkv),
-                    reinterpret_cast<_Float16*>(out), T, C, scale_log2);
+                    reinterpret_cast<_Float16*>(out), lse, T, C, scale_log2);
     } else {
         DDNM_LAUNCH((attn16_d64_kernel<2>), dim3(T / 64, nh, B), dim3(128), 0, s, reinterpret_cast<const _Float16*>(qkv),
-                    reinterpret_cast<_Float16*>(out), T, C, scale_log2);
+                    reinterpret_cast<_Float16*>(out), lse, T, C, scale_log2);
     }
     return 0;
+}
+
+extern "C" int ddnm_attn16_d64(const void* qkv, void* out, int32_t B, int32_t T, int32_t C, void* stream) {
+    return ddnm_attn16_d64_lse(qkv, out, nullptr, B, T, C, stream);
 }

@@ -25,7 +25,25 @@ __device__ __forceinline__ float silu_grad(float u) {      // d/du [u * sigmoid(
 // ------------------------------------------------------------------------------------------------
 constexpr int GNB_PIX_PER_THREAD = 32;
 
-__global__ void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dA, int dA_ups,
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+// four consecutive channels of an fp32 or fp16 NHWC tensor (element index `i4` counts groups of four)
+template <typename T> __device__ __forceinline__ f32x4 ld4(const T* __restrict__ p, size_t i4);
+template <> __device__ __forceinline__ f32x4 ld4<float>(const float* __restrict__ p, size_t i4) {
+    return reinterpret_cast<const f32x4*>(p)[i4];
+}
+template <> __device__ __forceinline__ f32x4 ld4<_Float16>(const _Float16* __restrict__ p, size_t i4) {
+    const half4_t h = reinterpret_cast<const half4_t*>(p)[i4];
+    return f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, size_t i4, f32x4 v) { reinterpret_cast<f32x4*>(p)[i4] = v; }
+__device__ __forceinline__ void st4(_Float16* __restrict__ p, size_t i4, f32x4 v) {
+    reinterpret_cast<half4_t*>(p)[i4] = half4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+
+// T = float: the fp32-tensor classifier path; T = _Float16: the fp16-activation path (activations AND their gradients
+// fp16 NHWC in HBM like the reference's `classifier_use_fp16` autograd, arithmetic and every reduction fp32 / fp64)
+template <typename T>
+__global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dA, int dA_ups,
                                      const float* __restrict__ sc, const float* __restrict__ sh,
                                      const float* __restrict__ mean_rstd, int silu, int H, int W, int C, int groups,
                                      double* __restrict__ partial, int nchunk, int pix_per_chunk) {
@@ -42,13 +60,13 @@ __global__ void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* _
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(sh + (size_t)b * C + c);
         const int p_end = min(HW, (chunk + 1) * pix_per_chunk);
         for (int p = chunk * pix_per_chunk + prow; p < p_end; p += rows) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((size_t)b * HW + p) * C + c);
+            const f32x4 xv = ld4<T>(x, ((size_t)b * HW + p) * C4 + c4);
             f32x4 d;
             if (dA_ups) {
                 const int yy = p / W, xx = p - yy * W;
-                d = *reinterpret_cast<const f32x4*>(dA + (((size_t)b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C + c) * 0.25f;
+                d = ld4<T>(dA, (((size_t)b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C4 + c4) * 0.25f;
             } else {
-                d = *reinterpret_cast<const f32x4*>(dA + ((size_t)b * HW + p) * C + c);
+                d = ld4<T>(dA, ((size_t)b * HW + p) * C4 + c4);
             }
             f32x4 u = xv * a + t0;
             if (silu) { d.x *= silu_grad(u.x); d.y *= silu_grad(u.y); d.z *= silu_grad(u.z); d.w *= silu_grad(u.w); }
@@ -109,13 +127,14 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __re
 }
 
 // dx = t - c1 - (x - mean)*c2  [+ add (optionally through the same half-resolution x0.25 mapping)]
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dA,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dA,
                                                            int dA_ups, const float* __restrict__ sc,
                                                            const float* __restrict__ sh,
                                                            const float* __restrict__ mean_rstd,
                                                            const float* __restrict__ coef, int silu,
-                                                           const float* __restrict__ add, int add_ups, int H, int W,
-                                                           int C, int groups, float* __restrict__ dx, size_t total4) {
+                                                           const T* __restrict__ add, int add_ups, int H, int W,
+                                                           int C, int groups, T* __restrict__ dx, size_t total4) {
     const int C4 = C >> 2, HW = H * W, cpg = C / groups;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C4) * 4;
@@ -127,15 +146,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const float c1 = coef[(b * groups + g) * 2], c2 = coef[(b * groups + g) * 2 + 1];
         const f32x4 a = *reinterpret_cast<const f32x4*>(sc + b * C + c);
         const f32x4 t0 = *reinterpret_cast<const f32x4*>(sh + b * C + c);
-        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 xv = ld4<T>(x, i);
         const int yy = p / W, xx = p - yy * W;
         const size_t half_idx = ((b * (H >> 1) + (yy >> 1)) * (size_t)(W >> 1) + (xx >> 1)) * C4 + (c >> 2);
-        f32x4 d = dA_ups ? reinterpret_cast<const f32x4*>(dA)[half_idx] * 0.25f : reinterpret_cast<const f32x4*>(dA)[i];
+        f32x4 d = dA_ups ? ld4<T>(dA, half_idx) * 0.25f : ld4<T>(dA, i);
         f32x4 u = xv * a + t0;
         if (silu) { d.x *= silu_grad(u.x); d.y *= silu_grad(u.y); d.z *= silu_grad(u.z); d.w *= silu_grad(u.w); }
         f32x4 r = d * a - c1 - (xv - mean) * c2;
-        if (add) r = r + (add_ups ? reinterpret_cast<const f32x4*>(add)[half_idx] * 0.25f : reinterpret_cast<const f32x4*>(add)[i]);
-        reinterpret_cast<f32x4*>(dx)[i] = r;
+        if (add) r = r + (add_ups ? ld4<T>(add, half_idx) * 0.25f : ld4<T>(add, i));
+        st4(dx, i, r);
     }
 }
 
@@ -149,10 +168,11 @@ extern "C" int ddnm_gn_bwd_nchunk(int32_t HW, int32_t C) {
     return (HW + pix - 1) / pix;
 }
 
-extern "C" int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, const float* gn_scale,
-                               const float* gn_shift, const float* mean_rstd, int32_t silu, const float* add,
-                               int32_t add_ups, int32_t B, int32_t H, int32_t W, int32_t C, int32_t groups,
-                               double* partial, int32_t nchunk, float* coef, float* dx, void* stream) {
+template <typename T>
+static int gn_bwd_launch(const T* x, const T* dA, int32_t dA_ups, const float* gn_scale,
+                         const float* gn_shift, const float* mean_rstd, int32_t silu, const T* add,
+                         int32_t add_ups, int32_t B, int32_t H, int32_t W, int32_t C, int32_t groups,
+                         double* partial, int32_t nchunk, float* coef, T* dx, void* stream) {
     if (!x || !dA || !gn_scale || !gn_shift || !mean_rstd || !partial || !coef || !dx) return DDNM_E_BADARG;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || groups <= 0 || groups > 64) return DDNM_E_BADARG;
     if (C % (groups * 4) || C / 4 > 1024) return DDNM_E_SHAPE;
@@ -161,13 +181,30 @@ extern "C" int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, 
     const int rows = bd / C4, pix = rows * GNB_PIX_PER_THREAD, HW = H * W;
     if (nchunk != (HW + pix - 1) / pix) return DDNM_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    DDNM_LAUNCH(gn_bwd_reduce_kernel, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), s, x, dA, dA_ups, gn_scale,
+    DDNM_LAUNCH(gn_bwd_reduce_kernel<T>, dim3(nchunk, B), dim3(bd), 2 * bd * sizeof(double), s, x, dA, dA_ups, gn_scale,
                 gn_shift, mean_rstd, silu, H, W, C, groups, partial, nchunk, pix);
     DDNM_LAUNCH(gn_bwd_finalize_kernel, dim3(B, groups), dim3(256), 0, s, partial, nchunk, mean_rstd, HW, C, groups, coef);
     const size_t total4 = (size_t)B * HW * C4;
-    DDNM_LAUNCH(gn_bwd_apply_kernel, GRID_1D(total4), dim3(256), 0, s, x, dA, dA_ups, gn_scale, gn_shift, mean_rstd,
+    DDNM_LAUNCH(gn_bwd_apply_kernel<T>, GRID_1D(total4), dim3(256), 0, s, x, dA, dA_ups, gn_scale, gn_shift, mean_rstd,
                 coef, silu, add, add_ups, H, W, C, groups, dx, total4);
     return 0;
+}
+
+extern "C" int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, const float* gn_scale,
+                               const float* gn_shift, const float* mean_rstd, int32_t silu, const float* add,
+                               int32_t add_ups, int32_t B, int32_t H, int32_t W, int32_t C, int32_t groups,
+                               double* partial, int32_t nchunk, float* coef, float* dx, void* stream) {
+    return gn_bwd_launch<float>(x, dA, dA_ups, gn_scale, gn_shift, mean_rstd, silu, add, add_ups, B, H, W, C, groups, partial,
+                                nchunk, coef, dx, stream);
+}
+
+extern "C" int ddnm_gn_bwd_h16(const void* x, const void* dA, int32_t dA_ups, const float* gn_scale,
+                               const float* gn_shift, const float* mean_rstd, int32_t silu, const void* add,
+                               int32_t add_ups, int32_t B, int32_t H, int32_t W, int32_t C, int32_t groups,
+                               double* partial, int32_t nchunk, float* coef, void* dx, void* stream) {
+    return gn_bwd_launch<_Float16>(reinterpret_cast<const _Float16*>(x), reinterpret_cast<const _Float16*>(dA), dA_ups,
+                                   gn_scale, gn_shift, mean_rstd, silu, reinterpret_cast<const _Float16*>(add), add_ups, B, H,
+                                   W, C, groups, partial, nchunk, coef, reinterpret_cast<_Float16*>(dx), stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,7 +237,8 @@ extern "C" int ddnm_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows
 // X[b][1+p] = act(h[b][p]) + pos[:,1+p], act = silu(GroupNorm(h)) folded as (sc, sh).  Only token 0 is read
 // from the attention output, so only its query matters.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pool_tokens_kernel(const float* __restrict__ h, const float* __restrict__ sc,
+template <typename TH>
+__global__ __launch_bounds__(256) void pool_tokens_kernel(const TH* __restrict__ h, const float* __restrict__ sc,
                                                           const float* __restrict__ sh, const float* __restrict__ pos,
                                                           float* __restrict__ X, int HW, int C) {
     const int b = blockIdx.x, T = HW + 1;
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const float* __restric
         const float a = sc[(size_t)b * C + c], t0 = sh[(size_t)b * C + c];
         float sum = 0.f;
         for (int p = 0; p < HW; ++p) {
-            const float v = silu_f(h[((size_t)b * HW + p) * C + c] * a + t0);
+            const float v = silu_f((float)h[((size_t)b * HW + p) * C + c] * a + t0);
             sum += v;
             X[((size_t)b * T + 1 + p) * C + c] = v + pos[(size_t)c * T + 1 + p];
         }
@@ -219,7 +257,16 @@ __global__ __launch_bounds__(256) void pool_tokens_kernel(const float* __restric
 extern "C" int ddnm_pool_tokens_f32(const float* h, const float* gn_scale, const float* gn_shift, const float* pos,
                                     float* X, int32_t B, int32_t HW, int32_t C, void* stream) {
     if (!h || !gn_scale || !gn_shift || !pos || !X || B <= 0 || HW <= 0 || C <= 0) return DDNM_E_BADARG;
-    DDNM_LAUNCH(pool_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, h, gn_scale, gn_shift, pos, X, HW, C);
+    DDNM_LAUNCH(pool_tokens_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, h, gn_scale, gn_shift, pos, X, HW, C);
+    return 0;
+}
+
+// the same over the fp16 NHWC activation of the fp16-activation classifier path (tokens stay fp32)
+extern "C" int ddnm_pool_tokens_h16(const void* h, const float* gn_scale, const float* gn_shift, const float* pos,
+                                    float* X, int32_t B, int32_t HW, int32_t C, void* stream) {
+    if (!h || !gn_scale || !gn_shift || !pos || !X || B <= 0 || HW <= 0 || C <= 0) return DDNM_E_BADARG;
+    DDNM_LAUNCH(pool_tokens_kernel<_Float16>, dim3(B), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const _Float16*>(h),
+                gn_scale, gn_shift, pos, X, HW, C);
     return 0;
 }
 
@@ -310,21 +357,30 @@ extern "C" int ddnm_pool_attn_bwd_f32(const float* qkv, const float* P, const fl
 }
 
 // d act[b][p][c] = dX[b][1+p][c] + dX[b][0][c] / HW
-__global__ __launch_bounds__(256) void pool_tokens_bwd_kernel(const float* __restrict__ dX, float* __restrict__ dact,
+template <typename T>
+__global__ __launch_bounds__(256) void pool_tokens_bwd_kernel(const float* __restrict__ dX, T* __restrict__ dact,
                                                               int HW, int C, size_t total) {
-    const int T = HW + 1;
+    const int Tk = HW + 1;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C);
         const size_t bp = i / C;
         const size_t b = bp / HW, p = bp - b * HW;
-        dact[i] = dX[(b * T + 1 + p) * C + c] + dX[(b * T) * C + c] / (float)HW;
+        dact[i] = (T)(dX[(b * Tk + 1 + p) * C + c] + dX[(b * Tk) * C + c] / (float)HW);
     }
 }
 
 extern "C" int ddnm_pool_tokens_bwd_f32(const float* dX, float* dact, int32_t B, int32_t HW, int32_t C, void* stream) {
     if (!dX || !dact || B <= 0 || HW <= 0 || C <= 0) return DDNM_E_BADARG;
     const size_t total = (size_t)B * HW * C;
-    DDNM_LAUNCH(pool_tokens_bwd_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, dX, dact, HW, C, total);
+    DDNM_LAUNCH(pool_tokens_bwd_kernel<float>, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, dX, dact, HW, C, total);
+    return 0;
+}
+
+extern "C" int ddnm_pool_tokens_bwd_h16(const float* dX, void* dact, int32_t B, int32_t HW, int32_t C, void* stream) {
+    if (!dX || !dact || B <= 0 || HW <= 0 || C <= 0) return DDNM_E_BADARG;
+    const size_t total = (size_t)B * HW * C;
+    DDNM_LAUNCH(pool_tokens_bwd_kernel<_Float16>, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, dX,
+                reinterpret_cast<_Float16*>(dact), HW, C, total);
     return 0;
 }
 

@@ -11,8 +11,16 @@ run on flipped / transposed weights, GroupNorm(+FiLM)+SiLU backward is `ddnm_gn_
 backward is four batched MFMA GEMMs + `softmax_bwd_rows`, AttentionPool2d has its own small kernels
 (csrc/backward.hip).  Weight gradients are never formed.  The state-dict (249 tensors, reference names,
 e.g. the public 256x256_classifier.pt) loads unchanged.
+
+Two engines: fp32 tensors (default; `convert_to_fp16()` under DDNM_CLS_GEN1=1 adds fp16 MFMA operands for the 3x3 / 1x1
+convolutions only) and, since round 5, the **fp16-activation path** `convert_to_fp16()` selects by default -- what the
+reference's `classifier_use_fp16: true` (configs/imagenet_256_cc.yml:44, unet.py:817-823) means: every activation AND
+every activation gradient in HBM is fp16 NHWC, convolutions and their data gradients are `ddnm_conv16`, attention is
+the fused `ddnm_attn16_d64` with a fused backward (`ddnm_attn16_d64_bwd`: no [T][T] tensor), GroupNorm backward is
+`ddnm_gn_bwd_h16`; statistics, softmax, the attention pool and the embeddings stay fp32.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -91,6 +99,7 @@ class EncoderUNetModel:
         self.film_total = off
         self.w = None
         self.use_fp16 = False          # set by convert_to_fp16(), like the reference's runner (diffusion.py:176-177)
+        self.h16 = False               # ... which selects the fp16-activation path unless DDNM_CLS_GEN1=1
         self._ws = None
 
     def _walk(self):
@@ -106,19 +115,40 @@ class EncoderUNetModel:
         return self
 
     def convert_to_fp16(self):
-        """`classifier.convert_to_fp16()` (diffusion.py:176-177, unet.py:817-823): the 3x3 convolutions of the
-        torso -- forward AND the data-gradient convolutions of the backward pass -- run on fp16 MFMA operands with
-        fp32 accumulation (csrc/conv_igemm_f16.hip); GroupNorm, attention, the pool and every gradient tensor in HBM
-        stay fp32.  The backward pass is linear in d(logits), so it is evaluated on 2^10 * d(logits) and rescaled at
-        the end: activation gradients of ~1e-6 would otherwise fall below fp16's normal range when staged."""
+        """`classifier.convert_to_fp16()` (diffusion.py:176-177, unet.py:817-823): the torso runs the fp16-ACTIVATION
+        path (`_forward_h16` / `_backward_h16`): activations and activation gradients fp16 NHWC in HBM, convolutions and
+        data-gradient convolutions on `ddnm_conv16`, fused attention forward / backward, fp32 GroupNorm statistics,
+        softmax, pool and embeddings.  The backward pass is linear in d(logits), so it is evaluated on 2^10 * d(logits)
+        and rescaled at the end: activation gradients of ~1e-6 would otherwise fall below fp16's normal range.
+        DDNM_CLS_GEN1=1 selects the first-generation form (fp32 tensors, fp16 MFMA operands for the convolutions)."""
         self.use_fp16 = True
+        self.h16 = os.environ.get("DDNM_CLS_GEN1") != "1"
         if self.w is not None:
-            self._pack_f16()
+            self._pack_h16() if self.h16 else self._pack_f16()
         return self
 
     def convert_to_fp32(self):
         self.use_fp16 = False
+        self.h16 = False
         return self
+
+    def _pack_h16(self):
+        """fp16 (O,ky,kx,I) weights of the fp16-activation path, forward and data-gradient (input / output channels
+        swapped, taps flipped) forms, Cout padded to 256 rows (ops.pack_conv_weight16); built on first use from the HOST
+        copy of the checkpoint."""
+        w = self.w
+        if "h16.ready" in w:
+            return
+        for name, raw in self._raw_host.items():
+            raw = raw.to(device=self.device, dtype=torch.float32)
+            if raw.dim() == 3:
+                raw = raw.unsqueeze(-1)
+            w[name + ".h16"] = ops.pack_conv_weight16(raw, cin_pad=(64 if raw.shape[1] < 64 else None))
+            w[name + ".dgrad.h16"] = ops.pack_conv_weight16(raw.permute(1, 0, 2, 3).flip(2, 3).contiguous())
+            if name.endswith(".skip_connection"):
+                p16 = w[name + ".h16"]
+                w[name + ".h16.flat"] = p16.reshape(p16.shape[0], -1).contiguous()   # the fused shortcut's [Cout][Cin]
+        w["h16.ready"] = True
 
     def _pack_f16(self):
         for key, raw in self._raw.items():
@@ -167,9 +197,11 @@ class EncoderUNetModel:
         g = lambda k: sd[k].detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
         w = {}
         self._raw = {}
+        self._raw_host = {}            # conv name -> HOST weight of the checkpoint (packed on demand by _pack_h16)
 
         def conv(name, raw, cin_pad=None):
             """forward weights and the data-gradient weights (input/output channels swapped, taps flipped)"""
+            self._raw_host[name] = sd[name + ".weight"].detach()
             if raw.dim() == 3:
                 raw = raw.unsqueeze(-1)
             w[name + ".weight"] = ops.pack_conv_weight(raw, cin_pad=cin_pad)
@@ -203,6 +235,7 @@ class EncoderUNetModel:
                     fb.append(g(n + ".emb_layers.1.bias"))
                     if L[1] != L[2]:
                         conv(n + ".skip_connection", g(n + ".skip_connection.weight"))
+                        w[n + ".out_plus_skip.bias"] = (g(n + ".out_layers.3.bias") + g(n + ".skip_connection.bias")).contiguous()
                 else:
                     w[n + ".norm.weight"], w[n + ".norm.bias"] = g(n + ".norm.weight"), g(n + ".norm.bias")
                     conv(n + ".qkv", g(n + ".qkv.weight"))
@@ -219,7 +252,7 @@ class EncoderUNetModel:
         self.w = w
         self._ws = None
         if self.use_fp16:
-            self._pack_f16()
+            self._pack_h16() if self.h16 else self._pack_f16()
         return self
 
     # ------------------------------------------------------------------ forward (optionally recording a tape)
@@ -291,6 +324,82 @@ class EncoderUNetModel:
             tape.append(("attn", n, x.t, qkv, S, k))
         return out
 
+    # ------------------------------------------------------------------ fp16-activation forward (csrc/conv16.hip)
+    def _conv3_16(self, key, cout, x, gn, **kw):
+        """3x3 convolution (or data-gradient convolution) of an fp16 NHWC tensor on ddnm_conv16, the GroupNorm affine +
+        swish of `gn` fused into its loader; images too small for a pixel tile (8 x 8) go through im2col + one GEMM."""
+        w16 = self.w[key]
+        t = x.t if isinstance(x, ops.Act) else x
+        B, H, W, cin = t.shape
+        if ops.conv16_supported(B, H, W, cin, cout, 3):
+            return ops.conv16(x, w16, cout, 3, gn=gn, gn_silu=True, **kw)
+        col = ops.im2col16(x, None, gn, True)
+        return ops.conv16(col, w16.reshape(w16.shape[0], 1, -1), cout, 1, **kw)
+
+    def _res_h16(self, n, L, x, film_all, tape):
+        w = self.w
+        cin, cout, mode = L[1], L[2], L[3]
+        k1 = {} if tape is not None else None
+        k2 = {} if tape is not None else None
+        gn1 = self._gn(x, n + ".in_layers.0", keep=k1)
+        b1, b2 = w[n + ".in_layers.2.bias"], w[n + ".out_layers.3.bias"]
+        xs = None
+        if mode == "down":          # AvgPool2d on both branches (unet.py:237-242)
+            hp = ops.gn_apply16(x, None, gn1, True, pool=True)
+            xs = ops.gn_apply16(x, None, None, False, pool=True)
+            h = self._conv3_16(n + ".in_layers.2.h16", cout, hp, None, bias=b1)
+        else:
+            h = self._conv3_16(n + ".in_layers.2.h16", cout, x, gn1, bias=b1)
+            if cin == cout:
+                xs = x.t
+        gn2 = self._gn(h, n + ".out_layers.0", film=film_all[:, self._film_off[n]:], keep=k2)
+        if xs is not None:
+            out = self._conv3_16(n + ".out_layers.3.h16", cout, h, gn2, bias=b2, res=xs)
+        else:
+            B, H, W, _ = h.t.shape
+            if ops.conv16_supported(B, H, W, cout, cout, 3):      # 1x1 shortcut fused as extra K chunks over the raw input
+                out = ops.conv16(h, w[n + ".out_layers.3.h16"], cout, 3, gn=gn2, gn_silu=True,
+                                 bias=w[n + ".out_plus_skip.bias"], skip=(x.t, None),
+                                 skip_weight=w[n + ".skip_connection.h16.flat"])
+            else:
+                xs = ops.conv16(x.t, w[n + ".skip_connection.h16"], cout, 1, bias=w[n + ".skip_connection.bias"],
+                                emit_stats=False).t
+                out = self._conv3_16(n + ".out_layers.3.h16", cout, h, gn2, bias=b2, res=xs)
+        if tape is not None:
+            tape.append(("res", n, L, x.t, h.t, k1, k2))
+        return out
+
+    def _attn_h16(self, n, x, tape):
+        w = self.w
+        B, H, W, C = x.t.shape
+        if self.head_ch != 64:
+            raise NotImplementedError("the fused attention kernels are built for 64-channel heads (the DDNM classifier)")
+        k = {} if tape is not None else None
+        gn = self._gn(x, n + ".norm", keep=k)
+        a = ops.gn_apply16(x, None, gn, False)
+        qkv = ops.conv16(a, w[n + ".qkv.h16"], 3 * C, 1, bias=w[n + ".qkv.bias"], emit_stats=False).t
+        lse = None if tape is None else torch.empty(B, C // 64, H * W, dtype=torch.float32, device=qkv.device)
+        o = ops.attn16(qkv, C, lse=lse)
+        out = ops.conv16(o, w[n + ".proj_out.h16"], C, 1, bias=w[n + ".proj_out.bias"], res=x)
+        if tape is not None:
+            tape.append(("attn", n, x.t, qkv, o, lse, k))
+        return out
+
+    def _forward_h16(self, x, film_all, tape):
+        """The torso on fp16 NHWC activations; returns the tensor the output head (GroupNorm, SiLU, pool) reads."""
+        w = self.w
+        n0 = "input_blocks.0.0"
+        h = ops.nchw_to_nhwc16(x.float().contiguous(), 64)
+        h = ops.conv16(h, w[n0 + ".h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
+        for prefix, layers in self._walk():
+            for j, Ld in enumerate(layers):
+                n = f"{prefix}.{j}"
+                if Ld[0] == "res":
+                    h = self._res_h16(n, Ld, h, film_all, tape)
+                elif Ld[0] == "attn":
+                    h = self._attn_h16(n, h, tape)
+        return h
+
     def forward(self, x, timesteps, tape=None):
         """logits [B, 1000]; with `tape` (a list) the activations needed by the backward pass are recorded."""
         if self.w is None:
@@ -304,6 +413,9 @@ class EncoderUNetModel:
         emb = ops.linear(emb, w["time_embed.0.weight"], w["time_embed.0.bias"])
         emb = ops.linear(emb, w["time_embed.2.weight"], w["time_embed.2.bias"], silu_in=True)
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
+        if self.use_fp16 and self.h16:
+            h = self._forward_h16(x, film_all, tape)
+            return self._head(h, x, tape)
         im2col = "input_blocks.0.0.weight.im2col" in w
         h = (ops.nchw_im2col3x3_pad if im2col else ops.nchw_to_nhwc_pad)(x.float().contiguous(), CIN_PAD)
         for prefix, layers in self._walk():
@@ -317,7 +429,13 @@ class EncoderUNetModel:
                     h = self._res(n, Ld, h, film_all, tape)
                 else:
                     h = self._attn(n, h, tape)
-        # out: GroupNorm -> SiLU -> AttentionPool2d
+        return self._head(h, x, tape)
+
+    def _head(self, h, x, tape):
+        """out: GroupNorm -> SiLU -> AttentionPool2d (unet.py:833-841, 22-51) over the fp32 or fp16 torso output."""
+        w = self.w
+        L = _lib.lib()
+        B = x.shape[0]
         kp = {} if tape is not None else None
         gn = self._gn(h, "out.0", keep=kp)
         C, HW = self.final_ch, self.pool_sp ** 2
@@ -328,8 +446,8 @@ class EncoderUNetModel:
         X = torch.empty(Mp, C, dtype=torch.float32, device=x.device)
         if Mp > B * T:
             ops.fill_(X[B * T:], 0.0)
-        check(L.ddnm_pool_tokens_f32(_p(h.t), _p(gn[0]), _p(gn[1]), _p(w["pool.pos"]), _p(X), B, HW, C, ops._stream()),
-              "ddnm_pool_tokens_f32")
+        tok = L.ddnm_pool_tokens_h16 if h.t.dtype == torch.float16 else L.ddnm_pool_tokens_f32
+        check(tok(_p(h.t), _p(gn[0]), _p(gn[1]), _p(w["pool.pos"]), _p(X), B, HW, C, ops._stream()), "ddnm_pool_tokens")
         qkv = torch.empty(Mp, 3 * C, dtype=torch.float32, device=x.device)
         ops.bgemm(X, w["pool.qkv.weight"], qkv, Mp, 3 * C, C, lda=C, ldb=C, ldc=3 * C, transb=True,
                   D=w["pool.qkv.bias"], ldd=0, beta=1.0)
@@ -395,6 +513,38 @@ class EncoderUNetModel:
         dn = ops.conv2d(dqkv, w[n + ".qkv.dgrad"], C, 1, weight_f16=self._w16(n + ".qkv.dgrad"))
         return self._gn_bwd(x, dn, k, False, add=dout)
 
+    # ------------------------------------------------------------------ backward of the fp16-activation path
+    def _gn_bwd16(self, x, dA, keep, silu, add=None, dA_ups=False, add_ups=False):
+        B, H, W, C = x.shape
+        L = _lib.lib()
+        nchunk = L.ddnm_gn_bwd_nchunk(H * W, C)
+        dx = torch.empty_like(x)
+        check(L.ddnm_gn_bwd_h16(_p(x), _p(dA), int(dA_ups), _p(keep["scale"]), _p(keep["shift"]), _p(keep["mean_rstd"]),
+                                int(silu), _p(add), int(add_ups), B, H, W, C, keep["groups"], _p(self._bwd_partial),
+                                nchunk, _p(self._bwd_coef), _p(dx), ops._stream()), "ddnm_gn_bwd_h16")
+        return dx
+
+    def _res_bwd16(self, rec, dout):
+        _, n, L, x, h1, k1, k2 = rec
+        cin, cout, mode = L[1], L[2], L[3]
+        da2 = self._conv3_16(n + ".out_layers.3.dgrad.h16", cout, dout, None, emit_stats=False).t
+        dh1 = self._gn_bwd16(h1, da2, k2, True)
+        da1 = self._conv3_16(n + ".in_layers.2.dgrad.h16", cin, dh1, None, emit_stats=False).t
+        if mode == "down":
+            return self._gn_bwd16(x, da1, k1, True, add=dout, dA_ups=True, add_ups=True)
+        skip = dout if cin == cout else ops.conv16(dout, self.w[n + ".skip_connection.dgrad.h16"], cin, 1,
+                                                   emit_stats=False).t
+        return self._gn_bwd16(x, da1, k1, True, add=skip)
+
+    def _attn_bwd16(self, rec, dout):
+        _, n, x, qkv, o, lse, k = rec
+        w = self.w
+        C = x.shape[3]
+        dO = ops.conv16(dout, w[n + ".proj_out.dgrad.h16"], C, 1, emit_stats=False).t
+        dqkv = ops.attn16_bwd(qkv, o, dO, lse)
+        dn = ops.conv16(dqkv, w[n + ".qkv.dgrad.h16"], C, 1, emit_stats=False).t
+        return self._gn_bwd16(x, dn, k, False, add=dout)
+
     def log_prob_grad(self, x, timesteps, y):
         """d/dx log_softmax(classifier(x, t))[y]  as NCHW [B, 3, R, R]."""
         L = _lib.lib()
@@ -424,13 +574,22 @@ class EncoderUNetModel:
         dX = torch.empty(Mp, C, dtype=torch.float32, device=x.device)
         ops.bgemm(dqkv, w["pool.qkv.weight"], dX, Mp, C, 3 * C, lda=3 * C, ldb=C, ldc=C, transb=False)
         dact = torch.empty_like(h_pre)
-        check(L.ddnm_pool_tokens_bwd_f32(_p(dX), _p(dact), B, HW, C, ops._stream()), "ddnm_pool_tokens_bwd_f32")
-        dh = self._gn_bwd(h_pre, dact, kp, True)
-        while tape:
-            rec = tape.pop()
-            dh = self._res_bwd(rec, dh) if rec[0] == "res" else self._attn_bwd(rec, dh)
         n = "input_blocks.0.0"
-        grad = ops.conv2d(dh, w[n + ".dgrad"], self.in_channels, 3, out_nchw=True)
+        if h_pre.dtype == torch.float16:            # fp16-activation path: gradients travel as fp16 NHWC tensors too
+            check(L.ddnm_pool_tokens_bwd_h16(_p(dX), _p(dact), B, HW, C, ops._stream()), "ddnm_pool_tokens_bwd_h16")
+            dh = self._gn_bwd16(h_pre, dact, kp, True)
+            while tape:
+                rec = tape.pop()
+                dh = self._res_bwd16(rec, dh) if rec[0] == "res" else self._attn_bwd16(rec, dh)
+            # data gradient of the input convolution: 3 output channels, fp32 NCHW (the small-Cout form of conv16)
+            grad = ops.conv16_out(dh, w[n + ".dgrad.h16"], self.in_channels)
+        else:
+            check(L.ddnm_pool_tokens_bwd_f32(_p(dX), _p(dact), B, HW, C, ops._stream()), "ddnm_pool_tokens_bwd_f32")
+            dh = self._gn_bwd(h_pre, dact, kp, True)
+            while tape:
+                rec = tape.pop()
+                dh = self._res_bwd(rec, dh) if rec[0] == "res" else self._attn_bwd(rec, dh)
+            grad = ops.conv2d(dh, w[n + ".dgrad"], self.in_channels, 3, out_nchw=True)
         if gscale != 1.0:
             check(L.ddnm_axpby_f32(_p(grad), None, _p(grad), grad.numel(), 1.0 / gscale, 0.0, ops._stream()),
                   "ddnm_axpby_f32")

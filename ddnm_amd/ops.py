@@ -563,13 +563,32 @@ def gn_stats16(t):
     return Act(t, stats, tiles)
 
 
-def attn16(qkv, C):
-    """Fused multi-head attention (head dim 64) over the legacy-ordered fp16 qkv tensor [B,H,W,3C] -> [B,H,W,C]."""
+def attn16(qkv, C, lse=None):
+    """Fused multi-head attention (head dim 64) over the legacy-ordered fp16 qkv tensor [B,H,W,3C] -> [B,H,W,C].
+    `lse` (fp32 [B, C/64, H*W], optional) receives the per-query base-2 log-sum-exp the backward pass needs."""
     B, H, W, C3 = qkv.shape
     assert C3 == 3 * C
     out = torch.empty(B, H, W, C, dtype=torch.float16, device=qkv.device)
-    check(_lib.lib().ddnm_attn16_d64(_p(_f16c(qkv, "qkv")), _p(out), B, H * W, C, _stream()), "ddnm_attn16_d64")
+    if lse is None:
+        check(_lib.lib().ddnm_attn16_d64(_p(_f16c(qkv, "qkv")), _p(out), B, H * W, C, _stream()), "ddnm_attn16_d64")
+    else:
+        if lse.dtype != torch.float32 or lse.numel() != B * (C // 64) * H * W or not lse.is_contiguous():
+            raise ValueError("attn16: lse must be a contiguous float32 tensor [B, C/64, H*W]")
+        check(_lib.lib().ddnm_attn16_d64_lse(_p(_f16c(qkv, "qkv")), _p(out), _p(lse), B, H * W, C, _stream()),
+              "ddnm_attn16_d64_lse")
     return out
+
+
+def attn16_bwd(qkv, o, dO, lse):
+    """Input gradient of `attn16`: dqkv fp16 [B,H,W,3C] from qkv, the forward output o, its gradient dO and lse; the
+    probabilities are recomputed tile by tile (csrc/attn16_bwd.hip), nothing of size [T][T] is stored."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty_like(lse)
+    check(_lib.lib().ddnm_attn16_d64_bwd(_p(_f16c(qkv, "qkv")), _p(_f16c(o, "o")), _p(_f16c(dO, "dO")), _p(lse), _p(dsum),
+                                         _p(dqkv), B, H * W, C, _stream()), "ddnm_attn16_d64_bwd")
+    return dqkv
 
 
 # ----------------------------------------------------------------------------- GroupNorm

@@ -28,7 +28,7 @@ extern "C" {
 #define DDNM_E_BADARG (-1)   /* null pointer / non-positive size / misaligned */
 #define DDNM_E_SHAPE (-2)    /* shape not supported by this kernel family */
 
-int ddnm_version(void);                 /* ABI version, currently 5 (bumped on every struct / prototype change) */
+int ddnm_version(void);                 /* ABI version, currently 6 (bumped on every struct / prototype change) */
 const char* ddnm_build_digest(void);    /* sha256 of the sources + flags this binary was built from (build.py) */
 int ddnm_sizeof(int which);             /* sizeof of 0: ddnm_conv_desc, 1: ddnm_gemm_desc, 2: ddnm_conv16_desc,
                                            3: ddnm_step_scalars as compiled into the binary (-1: unknown index) */
@@ -259,6 +259,14 @@ int ddnm_gn_stats_h16(const void* src, float* stats, int32_t B, int32_t HW, int3
  * qkv fp16 [B][T][3C] laid out head-major (channel = h*192 + {q,k,v}*64 + d), out fp16 [B][T][C]; fp32 softmax,
  * probabilities rounded to fp16 like `.type(weight.dtype)`; no [T][T] tensor in HBM.  T % 64 == 0, C % 64 == 0. */
 int ddnm_attn16_d64(const void* qkv, void* out, int32_t B, int32_t T, int32_t C, void* stream);
+/* ABI 6 -- the same, also writing lse[b][h][t] = log2 sum_s exp2(q_t . k_s * log2(e) / 8) (fp32 [B][C/64][T]) for the
+ * backward pass, and that backward pass (input gradient of AttentionBlock's attention inside the classifier-guidance
+ * gradient, diffusion.py:183-189): dqkv fp16 [B][T][3C] in the layout of qkv from qkv, the forward output o, its
+ * gradient dO (fp16 [B][T][C]) and lse; the probabilities are recomputed tile by tile, dsum [B][C/64][T] is scratch
+ * (rowsum(dO . o)).  No [T][T] tensor in HBM. */
+int ddnm_attn16_d64_lse(const void* qkv, void* out, float* lse, int32_t B, int32_t T, int32_t C, void* stream);
+int ddnm_attn16_d64_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* dsum, void* dqkv,
+                        int32_t B, int32_t T, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * GroupNorm statistics -> per-(sample, channel) affine for the conv prologue.
@@ -344,6 +352,13 @@ int ddnm_gn_bwd_f32(const float* x, const float* dA, int32_t dA_ups, const float
                     int32_t W, int32_t C, int32_t groups, double* partial /* [B][nchunk][groups][2] */, int32_t nchunk,
                     float* coef /* [B][groups][2] */, float* dx, void* stream);
 int ddnm_gn_bwd_nchunk(int32_t HW, int32_t C);
+/* ABI 6 -- the same for the fp16-activation classifier path (`classifier_use_fp16`, unet.py:817-823: the reference's
+ * autograd then carries activations AND their gradients in fp16): x, dA, add, dx fp16 NHWC; arithmetic fp32, the two
+ * group reductions fp64 in a fixed order. */
+int ddnm_gn_bwd_h16(const void* x, const void* dA, int32_t dA_ups, const float* gn_scale, const float* gn_shift,
+                    const float* mean_rstd, int32_t silu, const void* add, int32_t add_ups, int32_t B, int32_t H,
+                    int32_t W, int32_t C, int32_t groups, double* partial /* [B][nchunk][groups][2] */, int32_t nchunk,
+                    float* coef /* [B][groups][2] */, void* dx, void* stream);
 /* in place on dP: dS = scale * P .* (dP - rowsum(dP .* P)) */
 int ddnm_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);
 /* AttentionPool2d (unet.py:22-51): tokens, class-token attention (new qkv order), their backward, and the
@@ -356,6 +371,10 @@ int ddnm_pool_attn_bwd_f32(const float* qkv, const float* P, const float* da0, f
                            int32_t C, int32_t heads, void* stream);
 int ddnm_pool_tokens_bwd_f32(const float* dX, float* dact /* [B][HW][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
 int ddnm_logsoftmax_grad_f32(const float* logits, const int64_t* y, float* dlogits, int32_t B, int32_t N, void* stream);
+/* ABI 6 -- token construction / its backward over an fp16 NHWC activation (tokens and their gradient stay fp32) */
+int ddnm_pool_tokens_h16(const void* h, const float* gn_scale, const float* gn_shift, const float* pos /* [C][HW+1] */,
+                         float* X /* [B][HW+1][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
+int ddnm_pool_tokens_bwd_h16(const float* dX, void* dact /* fp16 [B][HW][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
 
 /* Row softmax in place: x[r][0..n) <- softmax(scale * x[r][:]); rows contiguous with ld. */
 int ddnm_softmax_rows_f32(float* x, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);

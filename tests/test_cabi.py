@@ -38,7 +38,7 @@ def test_prototypes_match_header():
 
 def test_version_and_error_strings(lib):
     from ddnm_amd import _lib
-    assert lib.ddnm_version() == _lib.ABI_VERSION == 5
+    assert lib.ddnm_version() == _lib.ABI_VERSION == 6
     assert b"shape" in lib.ddnm_error_string(-2)
     assert b"bad argument" in lib.ddnm_error_string(-1)
     assert lib.ddnm_error_string(0) == b"success"

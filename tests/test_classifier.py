@@ -73,16 +73,20 @@ def test_engine_classifier_logits_and_gradient(hip, kind, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["mid", "full"])
-def test_engine_classifier_fp16_operands(hip, kind, golden_dir):
-    """`classifier.convert_to_fp16()` (imagenet_256_cc.yml: classifier_use_fp16 true): forward and data-gradient 3x3
-    convolutions on fp16 MFMA operands, everything else fp32; checked against the fp32 autograd goldens of the
-    reference at the half-precision bar of SURVEY.md section 8c."""
+@pytest.mark.parametrize("kind,gen", [("small", "h16"), ("mid", "h16"), ("full", "h16"), ("mid", "gen1"), ("full", "gen1")])
+def test_engine_classifier_fp16_operands(hip, kind, gen, golden_dir, monkeypatch):
+    """`classifier.convert_to_fp16()` (imagenet_256_cc.yml: classifier_use_fp16 true) against the fp32 autograd goldens of
+    the reference at the half-precision bar of SURVEY.md section 8c.  "h16" (default since round 5): the fp16-ACTIVATION
+    path -- activations and activation gradients fp16 NHWC, ddnm_conv16 forward and data-gradient convolutions, fused
+    attention forward / backward, fp16 GroupNorm backward; "gen1" (DDNM_CLS_GEN1=1): fp32 tensors, fp16 MFMA operands
+    for the convolutions only."""
+    monkeypatch.setenv("DDNM_CLS_GEN1", "1" if gen == "gen1" else "0")
     g = np.load(f"{golden_dir}/classifier.npz")
     cc = weights.classifier_config(**KINDS[kind])
     x, t, y = _inputs(cc.image_size)
     m = _engine(cc, weights.classifier_state_dict(cc))
     m.convert_to_fp16()
+    assert m.h16 == (gen == "h16")
     logits = m(x.cuda(), t.cuda())
     torch.cuda.synchronize()
     err = rel(logits, torch.from_numpy(g[f"{kind}_logits"]))
@@ -125,6 +129,80 @@ def test_gn_backward_kernel(hip):
                             coef.data_ptr(), dx.data_ptr(), ops._stream()), "gn_bwd")
     torch.cuda.synchronize()
     assert rel(dx.cpu().permute(0, 3, 1, 2), ref) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,ups", [(128, 16, True), (128, 32, False), (384, 8, False), (512, 16, True)])
+def test_gn_backward_kernel_h16(hip, C, H, ups):
+    """ddnm_gn_bwd_h16 (fp16 activations and gradients, fp32 arithmetic) against torch autograd on the same fp16-rounded
+    inputs; the result is rounded to fp16 once."""
+    import torch.nn.functional as F
+    from ddnm_amd import _lib, ops
+    from ddnm_amd._lib import check
+    gen = torch.Generator().manual_seed(5)
+    B = 2
+    r16 = lambda t: t.half().float()       # noqa: E731
+    x = r16(torch.randn(B, C, H, H, generator=gen)).requires_grad_(True)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen)
+    Hd = H // 2 if ups else H
+    dA = r16(torch.randn(B, C, Hd, Hd, generator=gen))
+    add = r16(torch.randn(B, C, Hd, Hd, generator=gen))
+    a = F.silu(F.group_norm(x, 32, gamma, beta, eps=1e-5))
+    if ups:
+        a = F.avg_pool2d(a, 2, 2)
+    (a * dA).sum().backward()
+    ref = x.grad + (F.interpolate(add, scale_factor=2, mode="nearest") * 0.25 if ups else add)
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().half().cuda()      # noqa: E731
+    ws = ops.GroupNormWorkspace("cuda", B, C, B * ops.gn_nchunk(H * H, C) * 64)
+    keep = {}
+    xa = nh(x)
+    ops.group_norm_affine(xa, None, gamma.cuda(), beta.cuda(), 1e-5, ws, keep=keep)
+    L = _lib.lib()
+    nchunk = L.ddnm_gn_bwd_nchunk(H * H, C)
+    partial = torch.empty(B * nchunk * 64, dtype=torch.float64, device="cuda")
+    coef = torch.empty(B * 64, device="cuda")
+    dx = torch.empty(B, H, H, C, device="cuda", dtype=torch.float16)
+    da, ad = nh(dA), nh(add)
+    check(L.ddnm_gn_bwd_h16(xa.data_ptr(), da.data_ptr(), int(ups), keep["scale"].data_ptr(), keep["shift"].data_ptr(),
+                            keep["mean_rstd"].data_ptr(), 1, ad.data_ptr(), int(ups), B, H, H, C, 32, partial.data_ptr(),
+                            nchunk, coef.data_ptr(), dx.data_ptr(), ops._stream()), "gn_bwd_h16")
+    torch.cuda.synchronize()
+    err = rel(dx.float().cpu().permute(0, 3, 1, 2), ref)
+    assert err < 6e-4, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C", [(2, 64, 128), (1, 256, 256), (2, 1024, 64), (3, 128, 192)])
+def test_attention16_backward(hip, B, T, C):
+    """ddnm_attn16_d64_lse + ddnm_attn16_d64_bwd against torch autograd of QKVAttentionLegacy (unet.py:328-354) on the
+    same fp16-rounded qkv: output, log-sum-exp and the three input gradients."""
+    import math
+    from ddnm_amd import ops
+    gen = torch.Generator().manual_seed(31)
+    nh = C // 64
+    qkv = (0.8 * torch.randn(B, T, 3 * C, generator=gen)).half()
+    dO = torch.randn(B, T, C, generator=gen).half()
+    q32 = qkv.float().requires_grad_(True)
+    v = q32.view(B, T, nh, 3, 64)
+    q, k, vv = v[:, :, :, 0], v[:, :, :, 1], v[:, :, :, 2]                 # [B, T, nh, 64]
+    logits = torch.einsum("bthd,bshd->bhts", q, k) / 8.0
+    ref_lse = torch.logsumexp(logits, dim=-1) / math.log(2.0)                # base 2, [B, nh, T]
+    o_ref = torch.einsum("bhts,bshd->bthd", torch.softmax(logits, dim=-1), vv).reshape(B, T, C)
+    (o_ref * dO.float()).sum().backward()
+    side = int(math.isqrt(T))
+    H, W = (side, side) if side * side == T else (T // 8, 8)
+    qd = qkv.view(B, H, W, 3 * C).cuda()
+    lse = torch.empty(B, nh, T, device="cuda")
+    o = ops.attn16(qd, C, lse=lse)
+    dq = ops.attn16_bwd(qd, o, dO.view(B, H, W, C).cuda(), lse)
+    torch.cuda.synchronize()
+    assert rel(o.float().cpu().view(B, T, C), o_ref.detach()) < 2e-3
+    assert (lse.cpu() - ref_lse.detach()).abs().max().item() < 2e-3
+    g_ref = q32.grad.view(B, T, nh, 3, 64)
+    g_got = dq.float().cpu().view(B, T, nh, 3, 64)
+    for i, name in enumerate("qkv"):
+        err = rel(g_got[:, :, :, i], g_ref[:, :, :, i])
+        assert err < 4e-3, (name, err)
 
 
 @pytest.mark.gpu

@@ -118,10 +118,13 @@ def test_canary_adm_unet(hip, poisoned, monkeypatch, B, mode):
     _finish(poisoned, m(x, torch.full((B,), 770.0, device="cuda"), y))
 
 
-@pytest.mark.parametrize("B,fp16", [(1, False), (3, False), (3, True)])
-def test_canary_classifier_forward_backward(hip, poisoned, B, fp16):
+@pytest.mark.parametrize("B,fp16", [(1, False), (3, False), (3, "gen1"), (1, "h16"), (3, "h16"), (8, "h16")])
+def test_canary_classifier_forward_backward(hip, poisoned, monkeypatch, B, fp16):
+    """fp32 engine, first-generation fp16-operand engine (DDNM_CLS_GEN1=1) and the fp16-activation engine (round 5:
+    conv16 forward / data-gradient launches, fused attention forward + backward, fp16 GroupNorm backward)."""
     from ddnm_amd.guided_diffusion.classifier import create_classifier, make_cond_fn
     from oracle import weights
+    monkeypatch.setenv("DDNM_CLS_GEN1", "1" if fp16 == "gen1" else "0")
     cc = weights.classifier_config()
     clf = create_classifier(**{k: v for k, v in vars(cc).items() if k != "classifier_scale"})
     clf.load_state_dict(weights.classifier_state_dict(cc))
