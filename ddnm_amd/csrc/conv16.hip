@@ -618,6 +618,341 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
 }
 
 // =====================================================================================
+// 256 pixels x 128 output channels, FOUR waves per workgroup, TWO workgroups per CU (round 5).
+//
+// Launches with Cout = 128 (the classifier's 256^2 / 128^2 levels: 20 of its 42 forward + data-gradient 3x3 convolutions,
+// 72 % of its FLOPs) ran on the 256-channel tile above with half of the waves multiplying zero weight rows.  Their K loop
+// is short as well (Cin = 128: 18 taps), so with ONE workgroup per CU the tile prologue (halo fetch + GroupNorm) and the
+// epilogue (store-bound) are exposed for a third of the launch.  This kernel keeps the 128 x 64 wave tile (6 fragment
+// reads per 8 MFMAs) with 2 x 2 waves and fits TWO workgroups into a CU's LDS (77 KB each: ONE halo buffer, two weight
+// buffers), so the prologue / chunk hand-over / epilogue of one workgroup run under the MFMAs of the other; the CU still
+// holds 8 waves, 2 per SIMD.  Same LDS image, swizzle, fused GroupNorm-in-LDS and epilogue as conv16_kernel<9, 4, 4>;
+// no split-K, no fused shortcut (neither occurs at Cout = 128).
+// =====================================================================================
+struct N128Geom {
+    static constexpr int BM = 256, BN = 128, MT = 4, NT = 2, NWV = 4;
+    static constexpr int HROWS = 344, HGROUPS = HROWS / 8, HG_PER_WAVE = (HGROUPS + NWV - 1) / NWV;
+    static constexpr int HBYTES = HROWS * C16_ROWB, WBYTES = BN * C16_ROWB;
+    static constexpr int LDS_TILES = HBYTES + 2 * WBYTES;
+    static constexpr int LDS_MAIN = LDS_TILES + 512;
+    static constexpr int LDS_EPI = NWV * (MT * 32) * C16_EPITCH + 2 * BN * 2 * 4;
+    static constexpr int LDS_BYTES = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+};
+static_assert(2 * N128Geom::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+__global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p) {
+    using G = N128Geom;
+    constexpr int BM = G::BM, BN = G::BN, MT = G::MT, NT = G::NT;
+    __shared__ __attribute__((aligned(1024))) char lds[G::LDS_BYTES];
+    char* const Hb = lds;
+    char* const Wb = lds + G::HBYTES;
+    char* const Gb = lds + G::LDS_TILES;
+
+    const ddnm_conv16_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = lane >> 5;
+    const int m_tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int Cin = d.Cin;
+
+    const int img = m_tile / p.tiles_per_img;
+    const int TW = p.TW, TWl = p.TW_log2, HWd = TW + 2;
+    int ty0, tx0;
+    {
+        const int t = m_tile - img * p.tiles_per_img;
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        ty0 = ty * (BM >> TWl);
+        tx0 = tx << TWl;
+    }
+    const int NP = ((BM >> TWl) + 2) * HWd;
+
+    // ---- LDS-DMA source mapping: request group G = wave + 4*gi moves halo rows 8G .. 8G+7 (lane -> row 8G + lane/8,
+    // piece lane%8); (row >> 1) & 7 = ((G & 1) << 2) | (lrow >> 1) and G & 1 == wave & 1
+    const int lrow = lane >> 3, lpiece = lane & 7;
+    const int lp8 = (lpiece ^ (((wave & 1) << 2) | (lrow >> 1))) * 8;
+    // source pixel of halo row 8*(wave + 4*gi) + lrow, or -1 for zero padding / rows beyond the patch.  Evaluated where it
+    // is used (once per 64-channel chunk), NOT kept in 11 registers across the MFMA loop: the accumulators (128), two
+    // fragment sets (48) and the epilogue's residual tile leave no room (the first build spilled 34 registers); the empty
+    // asm keeps the compiler from hoisting the arithmetic out of the chunk loop again.
+    auto halo_src = [&](int gi) -> int {
+        int row = (wave + G::NWV * gi) * 8 + lrow;
+        asm volatile("" : "+v"(row));
+        int off = -1;
+        if (row < NP) {
+            const int hy = row / HWd, hx = row - hy * HWd;
+            const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+            if ((unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
+                const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
+                off = (img * p.Hs + sy) * p.Ws + sx;
+            }
+        }
+        return off;
+    };
+    // weight rows: 16 groups of 8 rows, wave w takes groups w, w+4, w+8, w+12
+    const unsigned wrow0 = (unsigned)(wave * 8 + lrow);
+    const unsigned src_pix = (unsigned)d.B * p.Hs * p.Ws;
+    const int C0 = d.src1 ? d.C0 : Cin, C1 = Cin - C0;
+    const __amdgpu_buffer_rsrc_t r_src = make_rsrc(d.src, src_pix * C0 * 2u);
+    const __amdgpu_buffer_rsrc_t r_src1 = make_rsrc(d.src1 ? d.src1 : d.src, src_pix * C1 * 2u);
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(d.weight, (unsigned)BN * 9u * Cin * 2u);
+    const unsigned wrow = 9u * (unsigned)Cin;
+
+    auto issue_halo = [&](int c) {
+        const int cb = c * C16_KC;
+        const bool first = cb < C0;
+        const __amdgpu_buffer_rsrc_t rsrc = first ? r_src : r_src1;
+        const unsigned cstride = first ? C0 : C1, coff = first ? cb : cb - C0;
+        char* dst = Hb + wave * 1024;
+#pragma unroll
+        for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) {
+            if (wave + G::NWV * gi < G::HGROUPS) {
+                const int ho = halo_src(gi);
+                const unsigned vo = ho >= 0 ? ((unsigned)ho * cstride + lp8) * 2u : C16_OOB;
+                bload16(rsrc, vo, coff * 2u, dst + gi * (G::NWV * 1024));
+            }
+        }
+    };
+    auto issue_w = [&](unsigned delta, int wb) {
+        char* dst = Wb + wb * G::WBYTES + wave * 1024;
+        const unsigned vo = (wrow0 * wrow + lp8) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bload16(r_w, vo, (delta + 32u * j * wrow) * 2u, dst + j * (G::NWV * 1024));
+    };
+    const bool fuse_gn = d.gn_scale != nullptr;
+    f32x4 gsc0, gsc1, gsh0, gsh1;
+    auto issue_gn = [&](int c) {
+        if (wave == 0 && lane < 16) {
+            const unsigned nb = (unsigned)d.B * Cin * 4u, vo = ((unsigned)(img * Cin + c * C16_KC) * 4u) + lane * 16u;
+            bload16(make_rsrc(d.gn_scale, nb), vo, 0u, Gb);
+            bload16(make_rsrc(d.gn_shift, nb), vo, 0u, Gb + 256);
+        }
+    };
+    auto read_gn = [&]() {
+        gsc0 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4); gsc1 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4 + 16);
+        gsh0 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4); gsh1 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4 + 16);
+    };
+    auto act_group = [&](int gi) {
+        if (wave + G::NWV * gi < G::HGROUPS && halo_src(gi) >= 0) {
+            char* pl = Hb + (wave + G::NWV * gi) * 1024 + lane * 16;
+            const half8 v = *reinterpret_cast<const half8*>(pl);
+            f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            f32x4 b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+            a = gn_act(a, gsc0, gsh0, d.gn_silu);
+            b = gn_act(b, gsc1, gsh1, d.gn_silu);
+            const half8 o = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                             (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+            *reinterpret_cast<half8*>(pl) = o;
+        }
+    };
+
+    // ---- fragment read addresses (bytes): A operand = weights (rows = output channels), B operand = pixels
+    int wa[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = wn * (NT * 32) + j * 32 + (lane & 31);
+        wa[j] = n * C16_ROWB + ((kh ^ ((n >> 1) & 7)) << 4);
+    }
+    int q0[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wm * MT + i) * 32 + (lane & 31);
+        q0[i] = (m >> TWl) * HWd + (m & (TW - 1));
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mfma_step = [&](int toff, int wb, auto&& after_first_kstep) {
+        int pb[MT], wo[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int q = q0[i] + toff;
+            pb[i] = q * C16_ROWB + ((kh ^ ((q >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wo[j] = wa[j] + G::HBYTES + wb * G::WBYTES;
+        half8 a[2][NT], b[2][MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[0][j] = *reinterpret_cast<const half8*>(lds + wo[j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[nxt][j] = *reinterpret_cast<const half8*>(lds + (wo[j] ^ ((ks + 1) << 5)));
+#pragma unroll
+                for (int i = 0; i < MT; ++i) b[nxt][i] = *reinterpret_cast<const half8*>(lds + (pb[i] ^ ((ks + 1) << 5)));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[cur][j], b[cur][i], acc[i][j], 0, 0, 0);
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int n = 0; n < MT + NT; ++n) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) {
+                after_first_kstep();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // ---- K loop: chunk = 64 input channels; ONE halo buffer (re-filled between chunks, behind a barrier: the other
+    // workgroup of the CU covers the gap), weight tiles double-buffered one tap ahead across chunk boundaries.
+    const int nchunks = Cin / C16_KC;
+    issue_halo(0);
+    if (fuse_gn) issue_gn(0);
+    issue_w(0u, 0);
+    int wb = 0;
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) {
+            __builtin_amdgcn_s_barrier();           // every wave has finished the previous chunk's fragment reads
+            issue_halo(c);
+            if (fuse_gn) issue_gn(c);
+        }
+        if (fuse_gn) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // the chunk's scale | shift (wave 0's requests) have landed
+            read_gn();
+#pragma unroll
+            for (int gi = 0; gi < G::HG_PER_WAVE; ++gi) act_group(gi);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const bool more = c + 1 < nchunks;
+        int toff = 0, kx = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // this tap's weight tile (tap 0: the halo too) is complete; wb ^ 1 is free
+            auto issue_next = [&]() {
+                if (tap + 1 < 9) issue_w((unsigned)((tap + 1) * Cin + c * C16_KC), wb ^ 1);
+                else if (more) issue_w((unsigned)((c + 1) * C16_KC), wb ^ 1);
+            };
+            mfma_step(toff, wb, issue_next);
+            wb ^= 1;
+            if (++kx == 3) { kx = 0; toff += HWd - 2; } else { ++toff; }
+        }
+    }
+
+    // ---- epilogue (as conv16_kernel, WNW = 4 form): residual tile requested before the LDS transposition
+    constexpr int ITS = MT * 32 / 8;
+    const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
+    _Float16* const out = reinterpret_cast<_Float16*>(d.out);
+    const float* const bias = d.bias;
+    const int cbase = wn * 64;
+    const int chn = cbase + lpiece * 8;
+    // output pixel of staging row it*8 + lrow of this wave (recomputed where it is needed: sixteen 64-bit addresses kept
+    // next to the accumulators and the residual tile were spilled to scratch)
+    auto out_pixel = [&](int it, int& rpix) -> int {
+        int m = wm * MT * 32 + it * 8 + lrow;
+        asm volatile("" : "+v"(m));
+        const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
+        rpix = d.res_ups ? (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1) : (img * d.H + oy) * d.W + ox;
+        return (img * d.H + oy) * d.W + ox;
+    };
+    // residual tile: the first half is requested NOW (its latency overlaps the barrier and the LDS transposition), the
+    // second half once the accumulators are dead -- all sixteen 16-byte pieces next to 128 accumulator registers do not
+    // fit the 256-register budget of two waves per SIMD
+    uint4 rv[ITS];
+    auto load_res = [&](int it) {
+        int rpix;
+        out_pixel(it, rpix);
+        rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
+    };
+    if (res) {
+#pragma unroll
+        for (int it = 0; it < ITS / 2; ++it) load_res(it);
+    }
+    __syncthreads();                   // all fragment reads done: LDS becomes the epilogue's staging area
+    char* const stage = lds + wave * (MT * 32) * C16_EPITCH;
+    float* const stat_lds = reinterpret_cast<float*>(lds + G::NWV * (MT * 32) * C16_EPITCH);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        f32x4 bias4[4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int ch = cbase + j * 32 + 8 * rg + 4 * kh;
+            bias4[rg] = bias ? *reinterpret_cast<const f32x4*>(bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 b4 = bias4[rg];
+                char* dst = stage + (i * 32 + (lane & 31)) * C16_EPITCH + (j * 32 + 8 * rg + 4 * kh) * 2;
+                half4 h = {(_Float16)(acc[i][j][4 * rg] + b4.x), (_Float16)(acc[i][j][4 * rg + 1] + b4.y),
+                           (_Float16)(acc[i][j][4 * rg + 2] + b4.z), (_Float16)(acc[i][j][4 * rg + 3] + b4.w)};
+                *reinterpret_cast<half4*>(dst) = h;
+            }
+    }
+    if (res) {
+#pragma unroll
+        for (int it = ITS / 2; it < ITS; ++it) load_res(it);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float cs[8], cq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        half8 v = *reinterpret_cast<const half8*>(stage + (it * 8 + lrow) * C16_EPITCH + lpiece * 16);
+        if (res) {
+            const half8 r8 = __builtin_bit_cast(half8, rv[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)r8[e]);
+        }
+        int rpix_unused;
+        const int pix = out_pixel(it, rpix_unused);
+        *reinterpret_cast<half8*>(out + (size_t)pix * d.Cout + chn) = v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            cs[e] += f;
+            cq[e] += f * f;
+        }
+    }
+    if (d.stats_out) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 8);  cq[e] += __shfl_xor(cq[e], 8);
+            cs[e] += __shfl_xor(cs[e], 16); cq[e] += __shfl_xor(cq[e], 16);
+            cs[e] += __shfl_xor(cs[e], 32); cq[e] += __shfl_xor(cq[e], 32);
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = wn * 64 + lane * 8 + e;
+                stat_lds[(wm * BN + c) * 2 + 0] = cs[e];
+                stat_lds[(wm * BN + c) * 2 + 1] = cq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const float a = stat_lds[tid * 2] + stat_lds[(BN + tid) * 2];
+            const float q = stat_lds[tid * 2 + 1] + stat_lds[(BN + tid) * 2 + 1];
+            *reinterpret_cast<float2*>(d.stats_out + ((size_t)m_tile * d.Cout + tid) * 2) = float2{a, q};
+        }
+    }
+}
+
+// =====================================================================================
 // split-K reduction: out(fp16) = round( sum_s ws[s] + bias + res ), + GroupNorm partials of the rounded values.
 // grid (B * tpi, ceil(Cout / 1024)); one workgroup per (image, pixel tile, 1024-channel slab); a thread owns one
 // float4 channel column and walks the tile's pixels (fixed order, no atomics).
@@ -833,7 +1168,14 @@ static bool slab16_enabled() {
 struct Plan16 {
     int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
     int fin_cs;          // > 0: the split-K reduction finalizes the consumer's GroupNorm, slabs of fin_cs channels
+    int n128;            // 1: conv16_n128_kernel (256 pixels x 128 channels, 4 waves, two workgroups per CU)
 };
+
+// 256 x 128 tiles for Cout = 128 (default); DDNM_P16_N128=0 keeps such launches on the 256-channel tile (A/B switch)
+static bool n128_enabled() {
+    static const bool on = [] { const char* e = getenv("DDNM_P16_N128"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 // channel slab of the finalizing reduction (0: this launch cannot / need not finalize): whole groups, 16 .. 64 channels,
 // images of at most 1024 pixels (one workgroup walks all of them)
@@ -866,6 +1208,7 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     if (d->ksize != 1 && d->ksize != 3) return false;
     pl->small = 0;
     pl->fin_cs = 0;
+    pl->n128 = 0;
     if (d->out_nchw_f32) {
         // fp32 NCHW output with <= 32 channels: 256-pixel x 32-channel tiles, no residual / shortcut / statistics
         if (d->ksize != 3 || d->Cout > 32 || d->ups || d->res || d->skip0 || d->stats_out) return false;
@@ -938,6 +1281,9 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
         if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;
+    // Cout = 128 on 256-pixel tiles, enough of them for two workgroups per CU to matter, no fused shortcut
+    pl->n128 = (pl->taps == 9 && best_mt == 4 && d->Cout == 128 && ks == 1 && !d->skip0 && pl->m_tiles >= 128 &&
+                n128_enabled()) ? 1 : 0;
     pl->fin_cs = fin_slab16(d, ks);
     if (pl->fin_cs > 0) pl->stats_tiles = 1;
     else if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
@@ -1020,6 +1366,8 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     const dim3 grid(pl.m_tiles * pl.n_tiles * pl.ksplit);
     if (pl.small) {
         DDNM_LAUNCH((conv16_kernel<9, 1, 1>), grid, dim3(512), 0, s, p);
+    } else if (pl.n128) {
+        DDNM_LAUNCH(conv16_n128_kernel, dim3(pl.m_tiles), dim3(256), 0, s, p);
     } else if (pl.taps == 9) {
         if (pl.MT == 4) { DDNM_LAUNCH((conv16_kernel<9, 4, 4>), grid, dim3(512), 0, s, p); }
         else { DDNM_LAUNCH((conv16_kernel<9, 2, 4>), grid, dim3(512), 0, s, p); }

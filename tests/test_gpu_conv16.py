@@ -89,6 +89,70 @@ def test_conv16_groupnorm_partials(hip, B, Cin, Cout, H, k):
     assert rel(got * sc[:, :, None, None] + sh[:, :, None, None], F.group_norm(got, 32, eps=1e-5)) < 2e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,kw", [
+    (4, 128, 128, 128, dict(res=True)),                      # 256 tiles of 8 x 32 pixels, two 64-channel chunks
+    (4, 64, 128, 128, dict()),                               # one chunk (the input convolution's shape class)
+    (4, 256, 128, 128, dict(res=True, bias=False)),          # four chunks (data gradient of a 128 -> 256 layer)
+    (1, 128, 128, 256, dict(res=True)),                      # one image at 256 x 256
+    (1, 128, 128, 256, dict(ups=True)),                      # operand through nearest x2
+    (4, 128, 128, 128, dict(res=True, res_ups=True)),
+])
+def test_conv16_n128_tile(hip, B, Cin, Cout, H, kw):
+    """Cout = 128 launches with >= 128 pixel tiles run conv16_n128_kernel (256 x 128 tile, 4 waves, two workgroups per
+    CU; round 5); the result equals the 256-channel-tile kernel's bit for bit (same products, same summation order per
+    output), GroupNorm partials included."""
+    out, _ = run_case(B, Cin, Cout, H, 3, **kw)
+    assert out.stats is not None and out.tiles == H * H // 256
+
+
+@pytest.mark.parametrize("B,C0,C1,H,silu,res", [(4, 128, 0, 128, True, True), (4, 64, 64, 128, True, False),
+                                               (1, 128, 0, 256, False, True), (5, 256, 0, 128, True, True)])
+def test_conv16_n128_fused_groupnorm(hip, B, C0, C1, H, silu, res):
+    """The n128 kernel's fused GroupNorm-in-LDS (single halo buffer, activated between chunks): equals the pre-pass
+    route bit for bit and the torch convolution of the fp16-rounded activated tensor."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(29)
+    Cin, Cout = C0 + C1, 128
+    a = torch.randn(B, C0, H, H, generator=g).half().float()
+    b = torch.randn(B, C1, H, H, generator=g).half().float() if C1 else None
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).half().float()
+    bias = torch.randn(Cout, generator=g)
+    sc, sh = torch.randn(B, Cin, generator=g), torch.randn(B, Cin, generator=g)
+    r = torch.randn(B, Cout, H, H, generator=g).half().float() if res else None
+    x = a if b is None else torch.cat([a, b], 1)
+    act = x * sc[:, :, None, None] + sh[:, :, None, None]
+    act = (F.silu(act) if silu else act).half().float()
+    ref = F.conv2d(act, w, bias, padding=1) + (r if res else 0)
+    gn = (sc.cuda().contiguous(), sh.cuda().contiguous())
+    w16 = ops.pack_conv_weight16(w.cuda())
+    out = ops.conv16(nhwc16(a), w16, Cout, 3, src1=None if b is None else nhwc16(b), gn=gn, gn_silu=silu, bias=bias.cuda(),
+                     res=None if r is None else nhwc16(r))
+    pre = ops.gn_apply16(nhwc16(a), None if b is None else nhwc16(b), gn, silu)
+    out2 = ops.conv16(pre, w16, Cout, 3, bias=bias.cuda(), res=None if r is None else nhwc16(r))
+    torch.cuda.synchronize()
+    assert rel(out.t.float().cpu().permute(0, 3, 1, 2), ref) < 8e-4
+    assert torch.equal(out.t, out2.t) and torch.equal(out.stats, out2.stats)
+
+
+def test_conv16_n128_equals_wide_tile(hip):
+    """A/B of the two kernels on one launch through the plan switch of a child process is not possible in-process (the
+    switch is read once); instead: the n128 result of a Cout = 128 layer equals rows 0..127 of the same layer padded to
+    Cout = 256 with zero weights, which runs on the 256-channel tile."""
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(30)
+    B, Cin, H = 4, 128, 128
+    x = nhwc16(torch.randn(B, Cin, H, H, generator=g))
+    w = (torch.randn(128, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5)
+    wpad = torch.cat([w, torch.zeros_like(w)], 0)
+    bias = torch.randn(128, generator=g)
+    a = ops.conv16(x, ops.pack_conv_weight16(w.cuda()), 128, 3, bias=bias.cuda())
+    b = ops.conv16(x, ops.pack_conv_weight16(wpad.cuda()), 256, 3, bias=torch.cat([bias, torch.zeros(128)]).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(a.t, b.t[..., :128].contiguous())
+    assert bool((b.t[..., 128:] == 0).all())
+
+
 def test_conv16_is_deterministic(hip):
     a, _ = run_case(2, 512, 512, 16, 3, res=True)
     b, _ = run_case(2, 512, 512, 16, 3, res=True)
