@@ -444,7 +444,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     // finished tile -- 16-byte stores, 8 lanes = one 128-byte line, half the bytes of an fp32 slab -- into slab `slice`;
     // bias / residual / statistics belong to the reduction pass.  (The fp32 form stores f32x4 per lane and pixel: 32-byte
     // segments.)  A partial sum rounded to fp16 carries 2^-12 of ITS OWN magnitude, the same order as the final rounding
-    // of the fp16 output tensor, so the result's error grows by about sqrt(2) (full-configuration goldens: tests).
+    // of the fp16 output tensor; with k slices the result's error grows by about sqrt(1 + k / 4) for partials of the sum's
+    // magnitude, which is why the host uses fp16 slabs for k <= 8 only (full-configuration goldens: tests).
     const bool partial16 = p.ksplit > 1 && p.slab16 != 0;
     const _Float16* const res = partial16 ? nullptr : reinterpret_cast<const _Float16*>(d.res);
     _Float16* const out = partial16 ? reinterpret_cast<_Float16*>(d.workspace) + (size_t)slice * p.M * d.Cout
@@ -653,7 +654,10 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int kh = lane >> 5;
-    const int m_tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    // workgroup -> (pixel tile, 128-channel tile); the channel tiles of one pixel tile are neighbours (same XCD: the
+    // second one finds the halo in L2)
+    const int q_wg = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m_tile = q_wg / p.n_tiles, n_tile = q_wg - m_tile * p.n_tiles;
     const int Cin = d.Cin;
 
     const int img = m_tile / p.tiles_per_img;
@@ -690,12 +694,12 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
         return off;
     };
     // weight rows: 16 groups of 8 rows, wave w takes groups w, w+4, w+8, w+12
-    const unsigned wrow0 = (unsigned)(wave * 8 + lrow);
+    const unsigned wrow0 = (unsigned)(n_tile * BN + wave * 8 + lrow);
     const unsigned src_pix = (unsigned)d.B * p.Hs * p.Ws;
     const int C0 = d.src1 ? d.C0 : Cin, C1 = Cin - C0;
     const __amdgpu_buffer_rsrc_t r_src = make_rsrc(d.src, src_pix * C0 * 2u);
     const __amdgpu_buffer_rsrc_t r_src1 = make_rsrc(d.src1 ? d.src1 : d.src, src_pix * C1 * 2u);
-    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(d.weight, (unsigned)BN * 9u * Cin * 2u);
+    const __amdgpu_buffer_rsrc_t r_w = make_rsrc(d.weight, (unsigned)p.n_tiles * BN * 9u * Cin * 2u);
     const unsigned wrow = 9u * (unsigned)Cin;
 
     auto issue_halo = [&](int c) {
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
     const _Float16* const res = reinterpret_cast<const _Float16*>(d.res);
     _Float16* const out = reinterpret_cast<_Float16*>(d.out);
     const float* const bias = d.bias;
-    const int cbase = wn * 64;
+    const int cbase = n_tile * BN + wn * 64;
     const int chn = cbase + lpiece * 8;
     // output pixel of staging row it*8 + lrow of this wave (recomputed where it is needed: sixteen 64-bit addresses kept
     // next to the accumulators and the residual tile were spilled to scratch)
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
         if (tid < BN) {
             const float a = stat_lds[tid * 2] + stat_lds[(BN + tid) * 2];
             const float q = stat_lds[tid * 2 + 1] + stat_lds[(BN + tid) * 2 + 1];
-            *reinterpret_cast<float2*>(d.stats_out + ((size_t)m_tile * d.Cout + tid) * 2) = float2{a, q};
+            *reinterpret_cast<float2*>(d.stats_out + ((size_t)m_tile * d.Cout + n_tile * BN + tid) * 2) = float2{a, q};
         }
     }
 }
@@ -1165,6 +1169,11 @@ static bool slab16_enabled() {
 }
 
 // ---------------------------------------------------------------------------------------------
+static bool n128_wide() {
+    static const bool on = [] { const char* e = getenv("DDNM_P16_N128_WIDE"); return e && e[0] == '1'; }();
+    return on;
+}
+
 struct Plan16 {
     int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
     int fin_cs;          // > 0: the split-K reduction finalizes the consumer's GroupNorm, slabs of fin_cs channels
@@ -1282,8 +1291,9 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     }
     pl->ksplit = ks;
     // Cout = 128 on 256-pixel tiles, enough of them for two workgroups per CU to matter, no fused shortcut
-    pl->n128 = (pl->taps == 9 && best_mt == 4 && d->Cout == 128 && ks == 1 && !d->skip0 && pl->m_tiles >= 128 &&
-                n128_enabled()) ? 1 : 0;
+    // (DDNM_P16_N128_WIDE=1, experiment: every Cout that is a multiple of 128, as Cout / 128 channel tiles)
+    pl->n128 = (pl->taps == 9 && best_mt == 4 && ks == 1 && !d->skip0 && pl->m_tiles >= 128 && n128_enabled() &&
+                (d->Cout == 128 || (n128_wide() && d->Cout % 128 == 0))) ? 1 : 0;
     pl->fin_cs = fin_slab16(d, ks);
     if (pl->fin_cs > 0) pl->stats_tiles = 1;
     else if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
@@ -1361,13 +1371,16 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     // weight bytes > activation bytes, and few enough pixel tiles per weight stream that one XCD's CUs do not all pull
     // the same weight lines at the same moment (32 sharers measured SLOWER than replicating the weights over XCDs)
     p.wmajor = ((long)d->Cout * pl.taps > (long)p.M && pl.m_tiles <= DDNM_P16_WMAJOR_MAXM) ? 1 : 0;
-    p.slab16 = slab16_enabled() ? 1 : 0;
+    // fp16 slabs for up to 8 slices only: every partial sum is rounded to fp16 once, so the added error grows like
+    // sqrt(ksplit) * 2^-12 of a partial's magnitude; deeper splits keep fp32 slabs
+    p.slab16 = (slab16_enabled() && pl.ksplit <= 8) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pl.m_tiles * pl.n_tiles * pl.ksplit);
     if (pl.small) {
         DDNM_LAUNCH((conv16_kernel<9, 1, 1>), grid, dim3(512), 0, s, p);
     } else if (pl.n128) {
-        DDNM_LAUNCH(conv16_n128_kernel, dim3(pl.m_tiles), dim3(256), 0, s, p);
+        p.n_tiles = d->Cout / 128;
+        DDNM_LAUNCH(conv16_n128_kernel, dim3(pl.m_tiles * p.n_tiles), dim3(256), 0, s, p);
     } else if (pl.taps == 9) {
         if (pl.MT == 4) { DDNM_LAUNCH((conv16_kernel<9, 4, 4>), grid, dim3(512), 0, s, p); }
         else { DDNM_LAUNCH((conv16_kernel<9, 2, 4>), grid, dim3(512), 0, s, p); }

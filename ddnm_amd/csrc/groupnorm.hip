@@ -7,6 +7,10 @@
 // guided_diffusion/nn.py:17-19,93-100.
 #include "conv_common.h"
 
+// max that PROPAGATES a non-finite operand as +inf (fmaxf drops NaN): the operand bounds of the split-fp16 kernels must
+// not underestimate when a partial is NaN
+__device__ __forceinline__ float nan_max(float q, float v) { return (v == v) ? fmaxf(q, v) : INFINITY; }
+
 constexpr int GN_PIX_PER_THREAD = 64;
 
 static inline int gn_block_dim(int C4) { return C4 <= 256 ? 256 : (C4 <= 512 ? 512 : 1024); }
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         const float2 v = *reinterpret_cast<const float2*>(part0 + (((size_t)b * tpi0 + t) * C0 + c) * 2);
         a += (double)v.x;
         q += (double)v.y;
-        qmax = fmaxf(qmax, v.y);
+        qmax = nan_max(qmax, v.y);
     }
     const int c1_lo = c_lo + n0 - C0;
     for (int it = tid; it < items1; it += 256) {
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
         const float2 v = *reinterpret_cast<const float2*>(part1 + (((size_t)b * tpi1 + t) * C1 + c) * 2);
         a += (double)v.x;
         q += (double)v.y;
-        qmax = fmaxf(qmax, v.y);
+        qmax = nan_max(qmax, v.y);
     }
     // fixed-shape reduction (deterministic): xor-butterfly inside each wave, then the four wave sums in order --
     // one barrier instead of the eight of an LDS tree (this kernel is pure latency: 101 launches per ADM forward)
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float* __r
     if ((tid & 63) == 0) { red[tid >> 6][0] = a; red[tid >> 6][1] = q; }
     __syncthreads();
     if (amax_out && tid == 64) {
-        // a NaN / inf partial propagates as inf: the consumer's result is non-finite either way
+        // a NaN / inf partial propagates as inf (nan_max: fmaxf alone would DROP a NaN operand): the consumer's result
+        // is non-finite either way
         const float m = fmaxf(fmaxf(qmax_s[0], qmax_s[1]), fmaxf(qmax_s[2], qmax_s[3]));
         amax_out[(size_t)b * groups + g] = sqrtf(m) * 1.0009765625f;        // (1 + 2^-10): rounding of the fp32 partial sums
     }
@@ -281,8 +286,8 @@ __global__ __launch_bounds__(256) void amax_bound_kernel(const float* __restrict
         float q = 0.f;
         for (int64_t j = lo + tid; j < hi; j += 256) {
             const f32x4 v = p[j];
-            if (kind) q = fmaxf(q, fmaxf(v.y, v.w));
-            else q = fmaxf(q, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            if (kind) q = nan_max(nan_max(q, v.y), v.w);
+            else q = nan_max(nan_max(nan_max(nan_max(q, fabsf(v.x)), fabsf(v.y)), fabsf(v.z)), fabsf(v.w));
         }
         m = fmaxf(m, kind ? sqrtf(q) * 1.0009765625f : q);
     };

@@ -39,10 +39,25 @@ def init(backend=None, force=False):
             # "nccl" is RCCL on ROCm; DDNM_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a 1-GPU box)
             backend = os.environ.get("DDNM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            # a world of one needs no agreed port: take a free one, so that two single-GPU jobs on one host (schedulers
+            # that export RANK=0 / WORLD_SIZE=1) cannot collide on 29500
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("MASTER_PORT", "29500")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        except Exception as e:      # noqa: BLE001
+            if world > 1:
+                raise
+            # a single rank needs no communication at all: a box without a usable RCCL / TCP store still runs
+            import warnings
+            warnings.warn(f"torch.distributed init failed for a world of one ({e!r}): running without a process group")
+            _COLLECTIVES_AT_WORLD_1 = False
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
     return rank, local_rank, world

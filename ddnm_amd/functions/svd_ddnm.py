@@ -135,11 +135,17 @@ class _GuidanceAhead:
         self.t_values, self.pos = t_values, 0
         self.serial = os.environ.get("DDNM_CLS_OVERLAP") == "0"
         # steps per guidance pass: DDNM_CLS_GROUP (default 4: c5 at B = 8 on one MI355X 2.92 / 3.00 / 3.03 / 3.04 images/s
-        # for 1 / 2 / 3 / 4, same box); DDNM_CLS_PAIR=0 is the step-by-step form
-        grp = int(os.environ.get("DDNM_CLS_GROUP", "4")) if os.environ.get("DDNM_CLS_PAIR", "1") != "0" else 1
-        # ... capped so that the replicated batch stays at <= 32 images: the classifier's largest fp32 activation
-        # (128 channels at 256 x 256) must stay below the 2 GiB a convolution launch can address
-        self.group = max(1, min(grp, len(t_values), max(1, 32 // n))) if (not self.serial and n > 0) else 1
+        # for 1 / 2 / 3 / 4, same box; 1 or 0 = step by step, bit-identical to the serial order; DDNM_CLS_PAIR=0 is the
+        # older spelling of that).  ONLY the engine's own cond_fn is grouped (`make_cond_fn` marks it): a foreign callable
+        # -- e.g. the reference's torch-autograd closure -- sees exactly the reference's calls (n images, one timestep),
+        # because grouping multiplies its activation memory by G and assumes a strictly per-sample classifier.
+        grp = int(os.environ.get("DDNM_CLS_GROUP", "4"))
+        if os.environ.get("DDNM_CLS_PAIR", "1") == "0" or grp < 1 or getattr(cls_fn, "ddnm_engine", None) is None:
+            grp = 1
+        # ... capped so that the replicated batch stays within what one convolution launch can address (2 GiB per
+        # tensor): 32 images for the fp32-tensor engines (128 channels at 256 x 256), 64 for the fp16-activation one
+        cap = int(getattr(getattr(cls_fn, "ddnm_engine", None), "max_group_batch", 32))
+        self.group = max(1, min(grp, len(t_values), max(1, cap // n))) if (not self.serial and n > 0) else 1
         self.queue = collections.deque()
         if self.group > 1:
             # per-run constants of the grouped evaluation, built on the main stream before the side stream forks: the

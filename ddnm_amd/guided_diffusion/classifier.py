@@ -107,6 +107,13 @@ class EncoderUNetModel:
             yield f"input_blocks.{i}", layers
         yield "middle_block", self.middle_block
 
+    @property
+    def max_group_batch(self):
+        """Images one pass may hold: the largest activation (model_channels at image_size^2) must stay below the 2 GiB a
+        convolution launch can address -- 4 bytes per element for the fp32-tensor engines, 2 for the fp16-activation one."""
+        per_image = self.image_size * self.image_size * self.model_channels * (2 if (self.use_fp16 and self.h16) else 4)
+        return max(1, (1 << 31) // per_image // 2)          # half of the addressable limit: 32 / 64 at 256 x 256 x 128
+
     # ------------------------------------------------------------------ nn.Module-like surface
     def to(self, device):
         return self
@@ -605,4 +612,7 @@ def make_cond_fn(classifier, classifier_scale):
             from ..functions.svd_operators import _axpby
             g = _axpby(g, None, float(classifier_scale), 0.0)
         return g
+    # marks the engine's own guidance function: ddnm_diffusion may evaluate several reverse steps per pass over a
+    # replicated batch (svd_ddnm.py::_GuidanceAhead); `max_group_batch` = images per pass the largest activation allows
+    cond_fn.ddnm_engine = classifier
     return cond_fn

@@ -273,9 +273,14 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     # fp16-operand MFMA path (the reference's use_fp16 torso) when packed fp16 weights are supplied and the
     # shape qualifies; everything else runs the exact-fp32 kernels
     f16, f16_1x1 = False, False
-    if skip is not None:        # the support queries below look at the shortcut's channel counts too
-        d.SC0 = (skip[0].t if isinstance(skip[0], Act) else skip[0]).shape[3]
-        d.SC1 = 0 if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1]).shape[3]
+    if skip is not None:
+        # the whole shortcut part of the descriptor is filled BEFORE the support queries below, so that every planner
+        # sees the descriptor the launch will see (some key on the pointer, some on the channel counts);
+        # skip_weight is chosen further down, once the kernel family is known
+        s0 = skip[0].t if isinstance(skip[0], Act) else skip[0]
+        s1 = None if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1])
+        d.skip0, d.skip1 = _p(s0), _p(s1)
+        d.SC0, d.SC1 = s0.shape[3], (0 if s1 is None else s1.shape[3])
     s16 = (weight_s16 is not None and weight_f16 is None and ksize == 3 and stride == 1
            and (skip is None or (weight_s16[2] is not None and gn is not None and d.SC0 % 32 == 0 and d.SC1 % 32 == 0))
            and L.ddnm_conv3x3_s16_supported(ctypes.byref(d)) == 1)
@@ -327,10 +332,6 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
             d.gn_scale, d.gn_shift, d.src_f16 = None, None, 1
     if skip is not None:
         # fused 1x1 shortcut; the caller has checked `conv_fuses_skip` (3x3 halo launch)
-        s0 = skip[0].t if isinstance(skip[0], Act) else skip[0]
-        s1 = None if skip[1] is None else (skip[1].t if isinstance(skip[1], Act) else skip[1])
-        d.skip0, d.skip1 = _p(s0), _p(s1)
-        d.SC0, d.SC1 = s0.shape[3], (0 if s1 is None else s1.shape[3])
         d.skip_weight = _p(skip_weight_f16) if f16 else (weight_s16[2].data_ptr() if s16 else _p(skip_weight))
         if f16 and skip_weight_f16 is None:
             raise ValueError("fp16 launch with a fused shortcut needs skip_weight_f16")

@@ -153,6 +153,25 @@ def test_conv16_n128_equals_wide_tile(hip):
     assert bool((b.t[..., 128:] == 0).all())
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,scale", [(4, 1024, 1024, 16, 40.0),      # 8 slices: fp16 slabs
+                                                 (1, 2048, 1024, 16, 40.0),      # 16 slices: fp32 slabs
+                                                 (2, 512, 512, 16, 200.0)])
+def test_conv16_splitk_large_magnitudes(hip, B, Cin, Cout, H, scale):
+    """Split-K partial sums of large activations: slices rounded to fp16 (<= 8 slices) or kept fp32 (deeper splits); the
+    result stays within one fp16 rounding of the fp32-accumulated reference and finite."""
+    import torch.nn.functional as F
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(41)
+    x = (scale * torch.randn(B, Cin, H, H, generator=g)).half().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).half().float()
+    ref = F.conv2d(x, w, None, padding=1)
+    out = ops.conv16(nhwc16(x), ops.pack_conv_weight16(w.cuda()), Cout, 3)
+    torch.cuda.synchronize()
+    got = out.t.float().cpu().permute(0, 3, 1, 2)
+    assert bool(torch.isfinite(got).all())
+    assert rel(got, ref) < 8e-4, rel(got, ref)
+
+
 def test_conv16_is_deterministic(hip):
     a, _ = run_case(2, 512, 512, 16, 3, res=True)
     b, _ = run_case(2, 512, 512, 16, 3, res=True)
