@@ -306,6 +306,15 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
                                           "GEMMs; GroupNorm / softmax / pooling not counted)" if cls_flops_per_image
                                           else "SURVEY estimate")
         res["guidance_stream"] = "second HIP stream, one reverse step ahead (DDNM_CLS_OVERLAP=0: serial)"
+    if roofline and rank == 0 and world == 1 and name == "c3" and not strong:
+        try:
+            def restore_small(b):
+                ddnm_diffusion(torch.randn(b, 3, 256, 256, device=dev), model, betas, 0.85, op, y[:b], cls_fn=None,
+                               classes=None, config=cfg, return_cpu=False)
+            res["latency"] = latency_probe(model, restore_small, lambda b: (torch.randn(b, 3, 256, 256, device=dev),
+                                                                             torch.full((b,), 500.0, device=dev)))
+        except Exception as e:    # noqa: BLE001
+            res["latency"] = {"error": repr(e)}
     if roofline and rank == 0 and B > 0:
         try:
             timer = ops.KernelTimer()
@@ -357,6 +366,51 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
             res["roofline"] = {"error": repr(e)}
     del model
     torch.cuda.empty_cache()
+    return res
+
+
+def latency_probe(model, restore, fwd_args, batches=(1, 2)):
+    """Small-batch operating point (the reference's shipped `sampling.batch_size: 1`): one full restoration at B = 1 / 2,
+    eager and with the forward replayed from a hipGraph (what `Diffusion` switches on for B <= 2), plus the host time to
+    ENQUEUE one eager forward against the GPU time of that forward.  `restore(B)` runs one restoration of B images and
+    returns after enqueueing; `fwd_args(B)` gives the arguments of one forward."""
+    res = {}
+    for B in batches:
+        ent = {}
+        for mode in ("eager", "graph"):
+            model.auto_graphs(2 if mode == "graph" else 0)
+            restore(B)                                   # warm-up (captures the graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            restore(B)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ent[mode] = {"images_per_s": round(B / dt, 4), "ms_per_restoration": round(dt * 1e3, 1)}
+        model.auto_graphs(0)
+        a = fwd_args(B)
+        for _ in range(2):
+            model(*a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model(*a)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        model.auto_graphs(2)
+        model(*a)
+        e0.record()
+        for _ in range(5):
+            model(*a)
+        e1.record()
+        torch.cuda.synchronize()
+        model.auto_graphs(0)
+        ent["forward"] = {"host_enqueue_ms_eager": round((t1 - t0) * 1e3, 3), "until_done_ms_eager": round((t2 - t0) * 1e3, 3),
+                          "gpu_ms_graph_replay": round(e0.elapsed_time(e1) / 5, 3)}
+        ent["graph_speedup"] = round(ent["graph"]["images_per_s"] / ent["eager"]["images_per_s"], 3)
+        res[f"b{B}"] = ent
+    res["note"] = ("one restoration each (T = 100), 1 warm-up; `graph` = the forward replayed from a captured hipGraph "
+                   "(ddnm_amd/graph.py), the runner's default for batch sizes <= 2 (DDNM_GRAPH_MAX_BATCH)")
     return res
 
 
@@ -575,6 +629,15 @@ def main():
             line["precision_check"] = precision_check(dev)
         except Exception as e:    # noqa: BLE001
             line["precision_check"] = {"error": repr(e)}
+    if world == 1 and not args.no_roofline and not args.no_side_path:
+        try:
+            def restore_small(b):
+                ddnm_diffusion(torch.randn(b, 3, 256, 256, device=dev), model, betas, 0.85, op, y[:b], cls_fn=None,
+                               classes=None, config=cfg, return_cpu=False)
+            line["latency"] = latency_probe(model, restore_small, lambda b: (torch.randn(b, 3, 256, 256, device=dev),
+                                                                              torch.full((b,), 500.0, device=dev)))
+        except Exception as e:    # noqa: BLE001
+            line["latency"] = {"error": repr(e)}
     if world == 1 and getattr(model, "split16", False) and not args.no_roofline and not args.no_side_path:
         # the same restoration (same noise) on the all-fp32-MFMA engine: its speed, and how far the two results are apart
         try:

@@ -112,7 +112,7 @@ class EncoderUNetModel:
         """Images one pass may hold: the largest activation (model_channels at image_size^2) must stay below the 2 GiB a
         convolution launch can address -- 4 bytes per element for the fp32-tensor engines, 2 for the fp16-activation one."""
         per_image = self.image_size * self.image_size * self.model_channels * (2 if (self.use_fp16 and self.h16) else 4)
-        return max(1, (1 << 31) // per_image // 2)          # half of the addressable limit: 32 / 64 at 256 x 256 x 128
+        return ops.max_launch_batch(per_image, margin=2)    # half of the addressable limit: 32 / 64 at 256 x 256 x 128
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def to(self, device):
@@ -413,6 +413,10 @@ class EncoderUNetModel:
             raise RuntimeError("load_state_dict() must be called before forward()")
         w = self.w
         B = x.shape[0]
+        mb = self.max_group_batch
+        if B > mb:                   # more images than one launch can address: micro-batches (no tape across chunks)
+            assert tape is None
+            return torch.cat([self.forward(x[i:i + mb], timesteps[i:i + mb]) for i in range(0, B, mb)], 0)
         self._workspace(B)
         L = _lib.lib()
         t = timesteps.to(device=x.device, dtype=torch.float32).contiguous()
@@ -557,6 +561,9 @@ class EncoderUNetModel:
         L = _lib.lib()
         w = self.w
         B = x.shape[0]
+        mb = self.max_group_batch
+        if B > mb:                   # micro-batches: forward + backward per chunk, gradients concatenated
+            return torch.cat([self.log_prob_grad(x[i:i + mb], timesteps[i:i + mb], y[i:i + mb]) for i in range(0, B, mb)], 0)
         tape = []
         logits = self.forward(x, timesteps, tape=tape)
         yy = y.to(device=x.device, dtype=torch.int64).contiguous().view(-1)

@@ -286,6 +286,10 @@ class Diffusion(object):
 
     def sample(self, simplified):
         model = self._build_model()
+        # batch sizes of 1 and 2 (the reference's shipped `sampling.batch_size: 1`) replay the forward from a hipGraph:
+        # eager, the host needs longer to enqueue a forward's ~250-300 launches than the GPU to run them
+        # (DDNM_GRAPH_MAX_BATCH=0 switches it off; bench.py `latency` reports both)
+        model.auto_graphs(int(os.environ.get("DDNM_GRAPH_MAX_BATCH", "2")))
         tt = self.config.time_travel
         print(("Run Simplified DDNM, without SVD." if simplified else "Run SVD-based DDNM."),
               f"{tt.T_sampling} sampling steps.", f"travel_length = {tt.travel_length},",

@@ -293,6 +293,7 @@ class Model:
         self._ws_by_stream = {}
         if getattr(self, "_graphs", None) is not None:
             self._graphs.reset()
+        self._auto_graphs = None
         return self
 
     def _guard_normalised_operands(self, sd, w):
@@ -407,9 +408,31 @@ class Model:
         self._graphs = None
         return self
 
+    def auto_graphs(self, max_batch=2):
+        """Replay forwards of at most `max_batch` images from a captured hipGraph, decided per call (0: never).  The
+        reference's shipped configs sample with batch_size 1 (configs/celeba_hq.yml:34-35); a forward is ~250 launches
+        whose host cost (~15 us each through ctypes) then exceeds their GPU time, and `cudnn.benchmark` was the
+        reference's own small-batch lever (main.py:145).  The runner (`Diffusion`) switches this on."""
+        self.auto_graph_max_batch = int(max_batch)
+        self._auto_graphs = None
+        return self
+
+    @property
+    def max_forward_batch(self):
+        """Chunk size of forward(): the largest activation is `ch` channels of fp32 at full resolution."""
+        return ops.max_launch_batch(self.resolution * self.resolution * self.ch * 4)
+
     def forward(self, x, t):
+        mb = self.max_forward_batch
+        if x.shape[0] > mb:          # more images than one launch can address: micro-batches, concatenated
+            return torch.cat([self.forward(x[i:i + mb], t[i:i + mb]) for i in range(0, x.shape[0], mb)], 0)
         if getattr(self, "_graphs", None) is not None:
             return self._graphs(x, t, None)
+        if x.shape[0] <= getattr(self, "auto_graph_max_batch", 0):
+            if getattr(self, "_auto_graphs", None) is None:
+                from ..graph import GraphedForward
+                self._auto_graphs = GraphedForward(lambda x_, t_, y_: self._forward_eager(x_, t_), two_streams=False)
+            return self._auto_graphs(x, t, None)
         return self._forward_eager(x, t)
 
     def _forward_eager(self, x, t):

@@ -298,6 +298,7 @@ class UNetModel:
         self._ws_by_stream = {}
         if self._graphs is not None:
             self._graphs.reset()
+        self._auto_graphs = None
         if self.use_fp16:
             self._pack_h16()
         return self
@@ -528,13 +529,37 @@ class UNetModel:
         self._graphs = None
         return self
 
+    def auto_graphs(self, max_batch=2):
+        """Replay forwards of at most `max_batch` images from a captured hipGraph, decided per call (0: never): the
+        reference's shipped configs sample with batch_size 1 (configs/imagenet_256.yml:42), where the ~300 launches of
+        a forward cost more host time than GPU time.  The runner (`Diffusion`) switches this on."""
+        self.auto_graph_max_batch = int(max_batch)
+        self._auto_graphs = None
+        return self
+
+    @property
+    def max_forward_batch(self):
+        """Chunk size of forward(): the largest activation is `model_channels` channels at full resolution (the skip
+        concat travels as two tensors), fp32 or -- in the fp16-activation mode -- fp16."""
+        elem = 2 if (self.use_fp16 and os.environ.get("DDNM_ADM_GEN1") != "1") else 4
+        return ops.max_launch_batch(self.image_size * self.image_size * self.model_channels * elem)
+
     def forward(self, x, timesteps, y=None):
         if self.w is None:
             raise RuntimeError("load_state_dict() must be called before forward()")
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
+        mb = self.max_forward_batch
+        if x.shape[0] > mb:          # more images than one launch can address: micro-batches, concatenated
+            return torch.cat([self.forward(x[i:i + mb], timesteps[i:i + mb], None if y is None else y[i:i + mb])
+                              for i in range(0, x.shape[0], mb)], 0)
         if self._graphs is not None:
             return self._graphs(x, timesteps, y)
+        if x.shape[0] <= getattr(self, "auto_graph_max_batch", 0):
+            if getattr(self, "_auto_graphs", None) is None:
+                from ..graph import GraphedForward
+                self._auto_graphs = GraphedForward(self._forward_eager, two_streams=False)
+            return self._auto_graphs(x, timesteps, y)
         return self._forward_eager(x, timesteps, y)
 
     def _forward_eager(self, x, timesteps, y=None):

@@ -55,6 +55,14 @@ def set_kernel_timer(t):
     _timer = t
 
 
+def max_launch_batch(per_image_bytes, margin=4):
+    """Largest batch whose biggest activation stays `margin` times below the 2 GiB one convolution launch can address
+    (32-bit byte offsets of the raw buffer descriptors, csrc/conv_common.h::conv_sizes_addressable): the models split a
+    larger batch into chunks of this size INSIDE forward() instead of refusing it (the reference: "you may increase the
+    batch_size to accelerate evaluation", README.md:89)."""
+    return max(1, (1 << 31) // int(per_image_bytes) // margin)
+
+
 # ----------------------------------------------------------------------------- convolution
 CONV_COUT_ALIGN = 128
 

@@ -92,3 +92,56 @@ def test_celeba_model_graph_replay_equals_eager(hip):
             torch.cuda.synchronize()
             assert torch.equal(out, e)
     m.disable_graphs()
+
+
+@pytest.mark.gpu
+def test_auto_graphs_small_batches_equal_eager(hip):
+    """`auto_graphs(2)` (what the runner switches on, guided_diffusion/diffusion.py::Diffusion.sample): forwards of one or
+    two images are replayed from a captured hipGraph and equal the eager forward bit for bit, larger batches stay eager;
+    a full small restoration through ddnm_diffusion gives the same image either way (celeba `Model` and the ADM UNet)."""
+    from ddnm_amd.functions.svd_ddnm import ddnm_diffusion
+    from ddnm_amd.guided_diffusion.models import Model
+    from ddnm_amd.guided_diffusion.unet import create_model
+    from oracle import cases, schedule
+    from tests.helpers import engine_operator
+    cfg, sd = cases.celeba_net("small")
+    m = Model(cfg)
+    m.load_state_dict(sd)
+    d = cfg.data.image_size
+    g = torch.Generator().manual_seed(7)
+    for B in (1, 2, 3):
+        x, t = torch.randn(B, 3, d, d, generator=g).cuda(), torch.full((B,), 430.0).cuda()
+        want = m(x, t).clone()
+        m.auto_graphs(2)
+        got = m(x, t)
+        got2 = m(x * 0.5, t)                 # a replay with other inputs ...
+        got3 = m(x, t)                       # ... and back
+        captured = m._auto_graphs is not None and any(k[0][0] == B for k in m._auto_graphs.entries)
+        m.auto_graphs(0)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got3, want) and not torch.equal(got2, want)
+        assert captured == (B <= 2)
+    cfg.time_travel.T_sampling, cfg.time_travel.travel_length, cfg.time_travel.travel_repeat = 6, 1, 1
+    n_it = len(schedule.jump_times(6, 1, 1)) - 1
+    x_orig, x_T, tape = cases.sampler_case(cfg, 1, n_it)
+    op = engine_operator("colorization", d)
+    y = cases.make_operator("colorization", d).A(x_orig).cuda()
+    outs = []
+    for mb in (0, 2):
+        m.auto_graphs(mb)
+        xs, _ = ddnm_diffusion(x_T.cuda(), m, cases.betas().cuda(), 0.85, op, y, cls_fn=None, classes=None, config=cfg,
+                               noise=[n.cuda() for n in tape], return_cpu=False)
+        outs.append(xs[0].clone())
+    assert torch.equal(outs[0], outs[1])
+    acfg, asd = cases.adm_net("small")
+    am = create_model(**vars(acfg.model))
+    am.load_state_dict(asd)
+    am.convert_to_fp16()
+    r = acfg.data.image_size
+    x, t = torch.randn(2, 3, r, r, generator=g).cuda(), torch.full((2,), 250.0).cuda()
+    yy = torch.tensor([3, 951]).cuda() if acfg.model.class_cond else None
+    want = am(x, t, yy).clone()
+    am.auto_graphs(2)
+    got = am(x, t, yy)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
