@@ -297,7 +297,13 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
            "scaling": "strong" if strong else "weak",
            "dtype": "f16 (activations and MFMA operands; f32 accumulate, GroupNorm statistics, softmax)",
            "data": "synthetic",
-           "config": {"workload": W["desc"], "global_batch": n_total, "per_gpu_batch": B, "nfe_per_image": nfe},
+           "config": {"workload": W["desc"], "global_batch": n_total, "per_gpu_batch": B, "nfe_per_image": nfe,
+                      # BASELINE quotes c3 on 8 GPUs and c4 on 4: only the strong line at THAT rank count reproduces the
+                      # configuration; at another N it is the same global batch on other shards (labelled)
+                      "baseline_ranks": W["ranks"],
+                      "reproduces_baseline_config": bool(world == W["ranks"] and (strong or W["ranks"] == 1)),
+                      "variant": (None if world == W["ranks"] or not strong else
+                                  f"BASELINE global batch {W['global_batch']} on {world} ranks instead of {W['ranks']}")},
            "whole_loop_tflops_per_gpu": round(tfl, 1), "whole_loop_frac": round(tfl / PEAK_F16_TFLOPS, 4),
            "finite": bool(torch.isfinite(out).all())}
     if name == "c5":

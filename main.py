@@ -7,8 +7,11 @@
 Flag names, defaults and side effects follow the reference (main.py:22-147): the image folder is
 `<exp>/image_samples/<-i>`, `--ni` overwrites it without asking, seeds are set for torch / numpy /
 the device generator, and any exception inside the run is logged while the process still exits 0
-(main.py:164-170).  Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N
-main.py ...` (one process per GPU); without torchrun it is a single-GPU run.
+(main.py:164-170).  Multi-GPU: like the reference, which takes every visible GPU from the plain command through
+nn.DataParallel (guided_diffusion/diffusion.py:140,164,180), `python main.py ...` on a node with N > 1 visible GPUs
+re-executes itself as N ranks (one process per GPU, `torch.distributed.run`; DDNM_GPUS=n picks another count,
+DDNM_GPUS=1 stays in this process); an explicit `python -m torch.distributed.run --nproc-per-node N main.py ...`
+works as before.
 
 `--path_y synthetic:N` (ours) replaces the dataset by N seeded uniform-noise images.
 """
@@ -116,7 +119,29 @@ def prepare_image_folder(args, rank):
     return True
 
 
+def maybe_self_launch(argv):
+    """Plain `python main.py ...` with several visible GPUs: re-exec as one rank per GPU (does not return then)."""
+    if "WORLD_SIZE" in os.environ or not torch.cuda.is_available():
+        return
+    ndev = torch.cuda.device_count()
+    n = int(os.environ.get("DDNM_GPUS", "0")) or ndev
+    if n <= 1:
+        return
+    if n > ndev and os.environ.get("DDNM_DIST_BACKEND") != "gloo":      # gloo: the 1-GPU test mode, ranks share the device
+        sys.stderr.write(f"[main] DDNM_GPUS={n} but only {ndev} GPU(s) are visible\n")
+        sys.exit(2)
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    sys.exit(subprocess.call(cmd))
+
+
 def main(argv=None):
+    maybe_self_launch(argv)
     args, config = parse_args_and_config(argv)
     try:
         from ddnm_amd import dist as ddist

@@ -190,3 +190,82 @@ def test_bench_self_launches_ranks_from_a_plain_command(hip):
     assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
     assert 0 < line["ms_per_step_rank_min"] <= line["ms_per_step"]
     assert line["value"] > 0 and line["consistency_max_abs"] < 1e-3
+
+
+def test_main_self_launches_ranks_from_a_plain_command(hip, tmp_path):
+    """`python main.py ...` with more than one GPU to use (DDNM_GPUS=2 here; every visible GPU by default) re-executes
+    itself as one rank per GPU -- the reference scales from the plain command too (nn.DataParallel,
+    guided_diffusion/diffusion.py:140,164,180).  The two ranks share this box's one GPU (gloo); the PNGs are those of the
+    single-process run."""
+    import subprocess
+    import sys
+    from PIL import Image
+    _reduced_yaml(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for n, folder in ((1, "solo"), (2, "duo")):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(DDNM_RANDOM_WEIGHTS="1", DDNM_DIST_BACKEND="gloo", PYTHONPATH=root, DDNM_GPUS=str(n))
+        r = subprocess.run([sys.executable, os.path.join(root, "main.py"), "--ni", "--config", "mini.yml", "--path_y",
+                            "synthetic:3", "--eta", "0.85", "--deg", "colorization", "--sigma_y", "0.", "-i", folder],
+                           cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert r.stdout.count("Total Average PSNR") == 1 and "Number of samples: 3" in r.stdout
+        outs[n] = r.stdout
+    d1, d2 = tmp_path / "exp" / "image_samples" / "solo", tmp_path / "exp" / "image_samples" / "duo"
+    names = sorted(p.name for p in d1.glob("*.png"))
+    assert names == sorted(p.name for p in d2.glob("*.png")) and len(names) == 3
+    for n in names:
+        a = np.asarray(Image.open(d1 / n), dtype=np.int16)
+        b = np.asarray(Image.open(d2 / n), dtype=np.int16)
+        assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-3, n
+
+
+def test_bench_eight_ranks_on_one_gpu(hip):
+    """The driver's first 8-GPU run must not be the first execution of the 8-rank path: `python bench.py --gpus 8` from a
+    plain command with the 8 ranks sharing this box's one MI355X (DDNM_DIST_BACKEND=gloo).  Exactly one JSON line,
+    n_gpus 8, ranks_seen 8 (an all_reduce of ones over the real group), the weak-scaling headline (8 images per rank),
+    the appended strong lines of BASELINE configs[2] (32 images -> 4 per rank = the BASELINE shard) and configs[3]
+    (16 images -> 2 per rank, labelled as a variant: BASELINE quotes it on 4 GPUs), all finite; the whole command stays
+    far inside the driver's 1800 s and the device memory of 8 replicated models fits the one GPU."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DDNM_DIST_BACKEND="gloo", PYTHONPATH=root)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1700)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak" and line["value"] > 0
+    w = line["workloads"]
+    assert w["c3"]["scaling"] == "strong" and w["c3"]["config"]["global_batch"] == 32 and w["c3"]["config"]["per_gpu_batch"] == 4
+    assert w["c3"]["config"]["reproduces_baseline_config"] is True and w["c3"]["finite"]
+    assert w["c4"]["config"]["global_batch"] == 16 and w["c4"]["config"]["per_gpu_batch"] == 2 and w["c4"]["finite"]
+    assert w["c4"]["config"]["reproduces_baseline_config"] is False and "4" in w["c4"]["config"]["variant"]
+    print(f"[8 ranks on one GPU] wall {wall:.0f} s; weak {line['value']:.2f} img/s, c3 {w['c3']['value']:.2f}, c4 {w['c4']['value']:.2f}")
+    assert wall < 1500
+
+
+def test_bench_four_ranks_reproduce_baseline_config3(hip):
+    """`--gpus 4 --workload c4 --scaling strong` = BASELINE configs[3] as quoted: 16 images on 4 GPUs (4 per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DDNM_DIST_BACKEND="gloo", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--workload", "c4", "--scaling", "strong",
+                        "--steps", "1", "--warmup", "0", "--no-roofline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 4 and line["ranks_seen"] == 4 and line["config"]["global_batch"] == 16
+    assert line["config"]["per_gpu_batch"] == 4 and line["config"]["reproduces_baseline_config"] is True
+    assert line["config"]["variant"] is None and line["finite"] and line["value"] > 0
