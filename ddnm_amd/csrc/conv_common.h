@@ -181,6 +181,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
                 cs[j] += v;
                 cq[j] += v * v;
             }
+            // 128 x 64 wave tiles (8 accumulator tiles live): keep the scheduler from interleaving the loads / stores of
+            // several tiles, which pushed the 4-wave split kernel over its 256-register budget (8 spilled registers)
+            if constexpr (MT * NT > 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
     }

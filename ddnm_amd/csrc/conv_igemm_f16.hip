@@ -55,10 +55,19 @@ constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 // operand of a launch without GroupNorm (Upsample convolution) and the fused shortcut's input -- are multiplied by a
 // per-launch, per-image power of two while they are split, and the accumulator by its inverse (conv_common.h::
 // s16_operand_scale).  Launches whose operands are all GroupNorm'd run the ASCALE = false instance (no multiply).
-template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false, bool ASCALE = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const ConvArgs p) {
+//
+// W4 (round 5; split form, <2, 2, 4, 2, ...>: FOUR waves, wave tile 128 x 64, the same 256 x 128 block) = TWO workgroups
+// per CU.  The counter-level attribution of the 8-wave form (profiles/r05_pmc_stalls_headline.md) books 37 % of all wave
+// cycles as parked at s_waitcnt / s_barrier -- with one workgroup per CU every wave of the CU parks at the SAME barrier,
+// so that time is lost on the matrix pipe (MFMA-busy 0.52) -- and 40 % as issue stalls behind the other wave's MFMAs.
+// Two independent workgroups per CU de-phase: one's barriers, chunk hand-overs and epilogue run under the other's MFMAs,
+// and the 128 x 64 wave tile needs 6 instead of 8 fragment reads per 8 MFMA triples.  To fit 2 x 80 KB of LDS the halo has
+// ONE buffer (re-staged between chunks behind a barrier: the other workgroup covers the gap) and the weights two.
+template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false, bool ASCALE = false, bool W4 = false>
+__global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_kernel(const ConvArgs p) {
     static_assert(!(SPLIT && SRC16), "the split form reads fp32 activations");
     static_assert(SPLIT || !ASCALE, "operand scaling belongs to the split form");
+    static_assert(!W4 || (SPLIT && WM * WN == 4), "the two-workgroups-per-CU form is the 4-wave split kernel");
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int MAXH = BM == 512 ? 612 : (BM == 256 ? 340 : (BM == 128 ? 204 : 136));
@@ -73,14 +82,17 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
     constexpr int BROWS_PER_PASS = NTHREADS / BCOLS;
     constexpr int BR = BN / BROWS_PER_PASS;                       // LDS-DMA instructions per wave and weight tile
     static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
-    constexpr int NWB = 3;                                        // weight tiles in LDS (tap, tap+1, tap+2)
+    constexpr int NWB = W4 ? 2 : 3;                               // weight tiles in LDS (tap, tap+1, tap+2; W4: tap, tap+1)
     constexpr int WTILE = BN * 128;                               // bytes of one weight tile
-    constexpr int HBYTES = 2 * MAXH * LDH * 2;                    // halo, double-buffered (see main loop)
-    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read)
-    __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + HBYTES + WM * BN * 2 * 4];
+    constexpr int HBYTES = (W4 ? 1 : 2) * MAXH * LDH * 2;         // halo, double-buffered (see main loop; W4: one buffer)
+    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read).
+    // W4: 2 x 16 KB + 48960 B = 81728 B, two workgroups per CU; the statistics scratch of the epilogue aliases the weight
+    // buffers (conv_epilogue synchronises before it writes them)
+    __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + HBYTES + (W4 ? 0 : WM * BN * 2 * 4)];
+    static_assert(!W4 || 2 * sizeof(lds_all) <= 160 * 1024, "two workgroups per CU");
     char* const Bs = lds_all;
     _Float16* const Hs = reinterpret_cast<_Float16*>(lds_all + NWB * WTILE);
-    float* const stat_lds = reinterpret_cast<float*>(lds_all + NWB * WTILE + HBYTES);
+    float* const stat_lds = reinterpret_cast<float*>(lds_all + (W4 ? 0 : NWB * WTILE + HBYTES));
 
     const ddnm_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,6 +319,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_f16_kernel(const Co
 #ifdef DDNM_PROBE_SETPRIO_HALF      // probe: the same for every form
     if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+    if constexpr (W4) {
+        // ---- two workgroups per CU: plain loop, every wait a full one (the other workgroup fills the gaps).
+        // [weights(tap) landed + halo writes visible | barrier | request weights(tap + 1) | MFMA(tap)]; between chunks:
+        // barrier (the halo is free) -> load, GroupNorm / swish / split, write the next chunk's halo.
+        if (c_begin < c_end) {
+            prefetch_halo(c_begin);
+            issue_w(c_begin, 0, 0);
+            stage_halo_part(0, 0, HR);
+            int wbuf = 0;
+            for (int chunk = c_begin; chunk < c_end; ++chunk) {
+                const bool more = chunk + 1 < c_end;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if (tap + 1 < 9) issue_w(chunk, tap + 1, wbuf ^ 1);
+                    else if (more) issue_w(chunk + 1, 0, wbuf ^ 1);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tap(tap, wbuf, 0);
+                    wbuf ^= 1;
+                }
+                if (more) {
+                    __builtin_amdgcn_s_barrier();          // every wave has finished this chunk's fragment reads
+                    asm volatile("" ::: "memory");
+                    prefetch_halo(chunk + 1);
+                    stage_halo_part(0, 0, HR);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         const int last_step = (c_end - c_begin) * 9 - 1;
@@ -501,6 +547,11 @@ static bool s16_unguarded_ok() {
     return ok;
 }
 
+static bool s16_w4_enabled() {
+    static const bool on = [] { const char* e = getenv("DDNM_S16_W4"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     const int kch = split ? KC16 / 2 : KC16;
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
@@ -549,6 +600,12 @@ static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
 #else
+    // split form with at least two workgroups per CU and no split-K: the 4-wave kernel, two workgroups per CU
+    // (DDNM_S16_W4=0: the 8-wave kernel everywhere, A/B switch)
+    if (split && pl.ksplit == 1 && (long)p.m_tiles * p.n_tiles >= 512 && s16_w4_enabled()) {
+        if (d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, true, true>), grid, dim3(256), 0, s, p); }
+        else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, false, true>), grid, dim3(256), 0, s, p); }
+    } else
     if (split && d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, true>), grid, dim3(512), 0, s, p); }
     else if (split) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>), grid, dim3(512), 0, s, p); }
     else if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
