@@ -630,6 +630,25 @@ def main():
         except Exception as e:    # noqa: BLE001
             ops.set_kernel_timer(None)
             line["roofline"] = {"error": repr(e)}
+    if rank == 0 and not args.no_roofline:
+        # hbm_frac = bytes / (t x 6.29 TB/s) of every HBM-bound kernel of the path (sampler steps,
+        # FWHT, re-noise, finalize, GroupNorm backward, small-Cout convolution, FiLM projection), and the counter-level
+        # stall attribution of the dominant kernels -- from separate rocprofv3 passes (tools/hbm_kernels.py,
+        # tools/pmc_stalls.py), reported only when the profile carries the loaded library's source digest
+        hit = pmc_for_loaded_binary(lib_digest, "_hbm_kernels.json")
+        if hit is not None:
+            line["roofline_hbm"] = {"source": f"profiles/{hit[0]}", "peak_TBps": hit[1].get("hbm_achievable_TBps"),
+                                    "note": hit[1].get("passes"),
+                                    "kernels": [{"kernel": k["kernel"], "bytes_algorithmic": k["bytes_algorithmic"],
+                                                 "bytes_pmc": k["bytes_pmc"], "us": k["us"],
+                                                 "frac_of_6.29TB/s": k["frac_of_6.29TBps"], "frac_pmc": k["frac_pmc"]}
+                                                for k in hit[1].get("kernels", [])]}
+        else:
+            line["roofline_hbm"] = {"note": "no profiles/*_hbm_kernels.json carries the loaded library's source digest"}
+        st = pmc_for_loaded_binary(lib_digest, "_pmc_stalls_headline.json")
+        if st is not None and "roofline" in line and isinstance(line["roofline"], dict):
+            line["roofline"]["stall_attribution"] = dict(st[1].get("all_launches", {}), source=f"profiles/{st[0]}",
+                                                         units=st[1].get("units"))
     if rank == 0 and getattr(model, "split16", False) and not args.no_roofline:
         try:
             line["precision_check"] = precision_check(dev)

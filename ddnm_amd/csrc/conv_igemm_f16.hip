@@ -548,7 +548,7 @@ static bool s16_unguarded_ok() {
 }
 
 static bool s16_w4_enabled() {
-    static const bool on = [] { const char* e = getenv("DDNM_S16_W4"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("DDNM_S16_W4"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -600,8 +600,9 @@ static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
 #else
-    // split form with at least two workgroups per CU and no split-K: the 4-wave kernel, two workgroups per CU
-    // (DDNM_S16_W4=0: the 8-wave kernel everywhere, A/B switch)
+    // DDNM_S16_W4=1 (A/B switch, off by default): split launches with at least two workgroups per CU and no split-K run
+    // the 4-wave kernel, two workgroups per CU.  Measured equal to the 8-wave kernel within +-3 % on every 256^2 / 128^2
+    // layer shape (tools/s16_probe.py time, same box): the launches are power-limited, see DESIGN.md section 3.0
     if (split && pl.ksplit == 1 && (long)p.m_tiles * p.n_tiles >= 512 && s16_w4_enabled()) {
         if (d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, true, true>), grid, dim3(256), 0, s, p); }
         else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, false, true>), grid, dim3(256), 0, s, p); }

@@ -109,7 +109,7 @@ def test_split_kernel_is_at_least_as_close_to_fp64_as_the_fp32_kernel(case):
     assert ((a16.t - a32.t).norm() / a32.t.norm()).item() < 1.5e-6
 
 
-# launches with >= 512 tiles and no split-K run the 4-wave form, two workgroups per CU (round 5):
+# DDNM_S16_W4=1: launches with >= 512 tiles and no split-K run the 4-wave form, two workgroups per CU (round 5):
 # B, C0, C1, Cout, H, ups, gn, res, skip, badd
 W4_CASES = [
     (8, 128, 0, 128, 128, 0, 1, 1, 0, 1),     # 512 tiles: GroupNorm + swish, temb addend, residual, 4 chunks
@@ -117,15 +117,15 @@ W4_CASES = [
     (2, 128, 0, 128, 128, 1, 0, 0, 0, 0),     # Upsample conv (raw operand: the operand-scale instance), output 256 x 256
     (4, 160, 0, 256, 128, 0, 1, 1, 0, 0),     # Cin = 5 chunks, two channel tiles
     (9, 32, 0, 128, 128, 0, 0, 0, 0, 0),      # ONE chunk (no chunk hand-over), ragged batch
-    (8, 128, 0, 128, 64, 0, 1, 1, 0, 0),      # 128 tiles only: stays on the 8-wave kernel (control)
+    (8, 128, 0, 128, 64, 0, 1, 1, 0, 0),      # 128 tiles only: stays on the 8-wave kernel either way (control)
 ]
 
 
 @pytest.mark.parametrize("case", W4_CASES)
 def test_four_wave_split_kernel_is_fp32_grade(case):
     """conv3x3_halo_f16_kernel<2, 2, 4, 2, .., W4>: same arithmetic as the 8-wave split kernel -- the result must be
-    BIT-IDENTICAL to it (same products, same summation order per output; checked against a child process that runs with
-    DDNM_S16_W4=0) and fp32 grade against fp64, GroupNorm partials included."""
+    BIT-IDENTICAL to it (same products, same summation order per output): this process runs the default 8-wave kernel, a
+    child process with DDNM_S16_W4=1 the 4-wave one; fp32 grade against fp64, GroupNorm partials included."""
     import os
     import subprocess
     import sys
@@ -143,7 +143,7 @@ def test_four_wave_split_kernel_is_fp32_grade(case):
         code = (f"import sys, torch; sys.path.insert(0, {root!r}); from tests import test_gpu_s16 as T\n"
                 f"t = T._make(*{case!r}, seed=11); a, _ = T._run(t, True); torch.cuda.synchronize()\n"
                 f"torch.save((a.t.cpu(), a.stats.cpu()), {td!r} + '/o.pt')\n")
-        env = dict(os.environ, DDNM_S16_W4="0", PYTHONPATH=root)
+        env = dict(os.environ, DDNM_S16_W4="1", PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         ot, ost = torch.load(td + "/o.pt")
