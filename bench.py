@@ -271,9 +271,17 @@ def adm_workload(name, ddist, rank, world, dev, steps, warmup, strong=False, roo
     times = get_schedule_jump(T_SAMPLING, *travel)
     nfe = sum(1 for a, b in zip(times[:-1], times[1:]) if b < a)
 
+    passes = [0]
+
     def one_pass():
-        x_T = torch.randn(max(B, 1), 3, 256, 256, device=dev)
-        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=cls_fn, classes=None, config=cfg, return_cpu=False)
+        # x_T and the per-iteration noise from the engine's own counter-based generator (in-kernel Philox draw: no ATen
+        # op in the timed loop); seed = pass number, counter = GLOBAL image index, so the noise of an image does not
+        # depend on the rank count
+        passes[0] += 1
+        ph = ops.PhiloxNoise(seed=0x5EED0000 + passes[0], image_base=(lo if strong else rank * B))
+        x_T = ph.tensor(ops.PhiloxNoise.XT_ITER, x_orig)
+        xs, _ = ddnm_diffusion(x_T, model, betas, 0.85, op, y, cls_fn=cls_fn, classes=None, config=cfg, return_cpu=False,
+                               noise=ph)
         return ddist.gather_images(xs[0][:B], n_total=n_total)
 
     for _ in range(warmup):
@@ -524,10 +532,16 @@ def main():
     y = op.A(x_orig)
     torch.cuda.manual_seed(1234 + rank)
 
-    def one_pass(m=None):
-        x_T = torch.randn(B, 3, 256, 256, device=dev)
+    passes = [0]
+
+    def one_pass(m=None, seed=None):
+        # x_T and the per-iteration noise from the engine's own counter-based generator (in-kernel Philox draw: no ATen
+        # op in the timed loop); counter = GLOBAL image index, so an image's noise does not depend on the rank count
+        passes[0] += 1
+        ph = ops.PhiloxNoise(seed=(0x5EED0000 + passes[0]) if seed is None else seed, image_base=rank * B)
+        x_T = ph.tensor(ops.PhiloxNoise.XT_ITER, x_orig)
         xs, _ = ddnm_diffusion(x_T, model if m is None else m, betas, 0.85, op, y, cls_fn=None, classes=None, config=cfg,
-                               return_cpu=False)
+                               return_cpu=False, noise=ph)
         return ddist.gather_images(xs[0])            # the path's single collective
 
     for _ in range(args.warmup):
@@ -557,6 +571,7 @@ def main():
                   "product, fp32 accumulate -- operand error 2^-22, measured closer to fp64 than the fp32 MFMA kernel; "
                   "everything else fp32)") if getattr(model, "split16", False) else "f32",
         "data": "synthetic",
+        "noise": "in-kernel Philox4x32-10 + Box-Muller (x_T and every iteration; no ATen RNG in the timed loop)",
         "config": {"workload": "celeba_hq.yml SVD sr_bicubic 4x, sigma_y=0, eta=0.85, T_sampling=100, "
                                "batch_size=8 per GPU (BASELINE configs[1])",
                    "global_batch": B * world, "image": "3x256x256", "parallelism": f"dp{world} (image sharding)"},
@@ -669,12 +684,10 @@ def main():
             model32 = Model(cfg, device=dev, split16=False)
             model32.load_state_dict(sd)
             one_pass(model32)                                   # warm-up
-            torch.cuda.manual_seed(4321)
-            out_s = one_pass()
-            torch.cuda.manual_seed(4321)
+            out_s = one_pass(seed=4321)                         # same seed: same x_T and noise for both engines
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            out_f = one_pass(model32)
+            out_f = one_pass(model32, seed=4321)
             torch.cuda.synchronize()
             dt32 = time.perf_counter() - t1
 

@@ -5,7 +5,7 @@ or a kernel returns an error, this module raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libddnm_hip.so")
@@ -68,7 +68,9 @@ class Conv16Desc(Structure):
 
 class StepScalars(Structure):
     _fields_ = [("sqrt_1m_at", c_float), ("sqrt_at", c_float), ("sqrt_at_next", c_float),
-                ("c1", c_float), ("c2", c_float), ("lam", c_float)]
+                ("c1", c_float), ("c2", c_float), ("lam", c_float),
+                ("rng_on", c_uint32), ("rng_seed_lo", c_uint32), ("rng_seed_hi", c_uint32), ("rng_iter", c_uint32),
+                ("rng_image_base", c_uint32), ("reserved_rng", c_uint32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/ddnm_hip.h declares
@@ -195,6 +197,7 @@ PROTOTYPES = {
                                        c_int32, c_void_p]),
     "ddnm_mul_planes_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
     "ddnm_fill_f32": (c_int32, [c_void_p, c_int64, c_float, c_void_p]),
+    "ddnm_randn_philox_f32": (c_int32, [c_void_p, c_int32, c_int64, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ddnm_op_upsample_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

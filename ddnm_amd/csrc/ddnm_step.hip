@@ -12,12 +12,31 @@
 // Rounding follows the reference's evaluation order; contraction into FMA is disabled so
 // that mul/add round separately like the ATen elementwise kernels.
 #include "common.h"
+#include "philox.h"
 #pragma clang fp contract(off)
 
 #define GRID_1D(n) dim3((unsigned)(((n) + 255) / 256 < 8192 ? ((n) + 255) / 256 : 8192))
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// Source of the step's N(0, I) noise: a tensor (explicit tape / ATen draw: the parity path) or, when `p` is NULL, the
+// in-kernel Philox draw of ddnm_step_scalars::rng_* (philox.h) -- element offset `off` (multiple of 4) into [B][chw].
+struct NoiseSrc {
+    const float* p;
+    PhiloxKey key;
+    unsigned iter, img_base;
+    int64_t chw;
+};
+static inline NoiseSrc noise_src(const float* noise, const ddnm_step_scalars* s, int64_t chw) {
+    return NoiseSrc{noise, PhiloxKey{s->rng_seed_lo, s->rng_seed_hi}, s->rng_iter, s->rng_image_base, chw};
+}
+static inline bool noise_ok(const float* noise, const ddnm_step_scalars* s) { return noise != nullptr || s->rng_on != 0; }
+__device__ __forceinline__ f32x4 nz4(const NoiseSrc& n, int64_t off) {
+    if (n.p) return ld4(n.p + off);
+    const int64_t b = off / n.chw, r = off - b * n.chw;
+    return philox_normal4(n.key, (unsigned)(r >> 2), n.iter, n.img_base + (unsigned)b);
+}
 
 __device__ __forceinline__ f32x4 x0_of(f32x4 xt, f32x4 et, const ddnm_step_scalars& s) {
     return (xt - et * s.sqrt_1m_at) / s.sqrt_at;
@@ -48,7 +67,7 @@ extern "C" int ddnm_step_x0_f32(const float* xt, const float* et, int64_t et_bst
 
 __global__ __launch_bounds__(256) void step_combine_kernel(const float* __restrict__ x0, const float* __restrict__ proj,
                                                            const float* __restrict__ apy,
-                                                           const float* __restrict__ noise,
+                                                           NoiseSrc noise,
                                                            const float* __restrict__ et, int64_t et_bstride,
                                                            float* __restrict__ xt_next, int64_t chw4, int64_t total4,
                                                            ddnm_step_scalars s) {
@@ -57,17 +76,17 @@ __global__ __launch_bounds__(256) void step_combine_kernel(const float* __restri
         f32x4 p = ld4(proj + i * 4);
         if (apy) p = p - ld4(apy + i * 4);
         const f32x4 x0h = ld4(x0 + i * 4) - p * s.lambda;
-        st4(xt_next + i * 4, update_of(x0h, ld4(noise + i * 4), ld4(et + b * et_bstride + r * 4), s));
+        st4(xt_next + i * 4, update_of(x0h, nz4(noise, i * 4), ld4(et + b * et_bstride + r * 4), s));
     }
 }
 
 extern "C" int ddnm_step_combine_f32(const float* x0, const float* proj, const float* apy, const float* noise,
                                      const float* et, int64_t et_bstride, float* xt_next, int32_t B, int64_t chw,
                                      const ddnm_step_scalars* s, void* stream) {
-    if (!x0 || !proj || !noise || !et || !xt_next || !s || B <= 0 || chw <= 0) return DDNM_E_BADARG;
+    if (!x0 || !proj || !et || !xt_next || !s || B <= 0 || chw <= 0 || !noise_ok(noise, s)) return DDNM_E_BADARG;
     if ((chw & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * chw / 4;
-    DDNM_LAUNCH(step_combine_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, x0, proj, apy, noise,
+    DDNM_LAUNCH(step_combine_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, x0, proj, apy, noise_src(noise, s, chw),
                        et, et_bstride, xt_next, chw / 4, total4, *s);
     return 0;
 }
@@ -75,7 +94,7 @@ extern "C" int ddnm_step_combine_f32(const float* x0, const float* proj, const f
 // ---------------------------------------------------------------- fused: SR by average pooling, r = 4
 // one thread per 4x4 patch: 4 rows x float4.
 __global__ __launch_bounds__(256) void step_sr4_kernel(const float* __restrict__ xt, const float* __restrict__ et,
-                                                       int64_t et_bstride, const float* __restrict__ noise,
+                                                       int64_t et_bstride, NoiseSrc noise,
                                                        const float* __restrict__ y, float* __restrict__ x0o,
                                                        float* __restrict__ xn, int H, int W, int64_t total,
                                                        ddnm_step_scalars s) {
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(256) void step_sr4_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) {
             if (x0o) st4(x0o + off + (int64_t)j * W, x0[j]);
             const f32x4 x0h = x0[j] - corr;
-            st4(xn + off + (int64_t)j * W, update_of(x0h, ld4(noise + off + (int64_t)j * W), e[j], s));
+            st4(xn + off + (int64_t)j * W, update_of(x0h, nz4(noise, off + (int64_t)j * W), e[j], s));
         }
     }
 }
@@ -111,10 +130,11 @@ __global__ __launch_bounds__(256) void step_sr4_kernel(const float* __restrict__
 extern "C" int ddnm_step_sr_avgpool_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                                         const float* y, float* x0, float* xt_next, int32_t B, int32_t H, int32_t W,
                                         int32_t r, const ddnm_step_scalars* s, void* stream) {
-    if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0) return DDNM_E_BADARG;
+    if (!xt || !et || !y || !xt_next || !s || B <= 0 || !noise_ok(noise, s)) return DDNM_E_BADARG;
     if (r != 4 || (H & 3) || (W & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total = (int64_t)B * 3 * (H / 4) * (W / 4);
-    DDNM_LAUNCH(step_sr4_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride, noise,
+    DDNM_LAUNCH(step_sr4_kernel, GRID_1D(total), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
+                noise_src(noise, s, (int64_t)3 * H * W),
                        y, x0, xt_next, H, W, total, *s);
     return 0;
 }
@@ -133,7 +153,7 @@ static ColorW color_weights(const float* w3_host) {
 }
 
 __global__ __launch_bounds__(256) void step_color_kernel(const float* __restrict__ xt, const float* __restrict__ et,
-                                                         int64_t et_bstride, const float* __restrict__ noise,
+                                                         int64_t et_bstride, NoiseSrc noise,
                                                          const float* __restrict__ y, float* __restrict__ x0o,
                                                          float* __restrict__ xn, int64_t hw4, int64_t total4,
                                                          ddnm_step_scalars s, ColorW cw) {
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256) void step_color_kernel(const float* __restrict
         for (int c = 0; c < 3; ++c) {
             if (x0o) st4(x0o + base + c * hw4 * 4, x0[c]);
             const f32x4 x0h = x0[c] - resid * cw.wp[c];
-            st4(xn + base + c * hw4 * 4, update_of(x0h, ld4(noise + base + c * hw4 * 4), e[c], s));
+            st4(xn + base + c * hw4 * 4, update_of(x0h, nz4(noise, base + c * hw4 * 4), e[c], s));
         }
     }
 }
@@ -160,17 +180,17 @@ __global__ __launch_bounds__(256) void step_color_kernel(const float* __restrict
 extern "C" int ddnm_step_color_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                                    const float* y, float* x0, float* xt_next, int32_t B, int32_t HW,
                                    const float* w3_host, const ddnm_step_scalars* s, void* stream) {
-    if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0 || HW <= 0) return DDNM_E_BADARG;
+    if (!xt || !et || !y || !xt_next || !s || B <= 0 || HW <= 0 || !noise_ok(noise, s)) return DDNM_E_BADARG;
     if ((HW & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * HW / 4;
     DDNM_LAUNCH(step_color_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
-                       noise, y, x0, xt_next, (int64_t)HW / 4, total4, *s, color_weights(w3_host));
+                       noise_src(noise, s, (int64_t)3 * HW), y, x0, xt_next, (int64_t)HW / 4, total4, *s, color_weights(w3_host));
     return 0;
 }
 
 // ---------------------------------------------------------------- fused: inpainting (mask as rank table)
 __global__ __launch_bounds__(256) void step_inpaint_kernel(const float* __restrict__ xt, const float* __restrict__ et,
-                                                           int64_t et_bstride, const float* __restrict__ noise,
+                                                           int64_t et_bstride, NoiseSrc noise,
                                                            const float* __restrict__ y, const int* __restrict__ rank,
                                                            int n_kept, float* __restrict__ x0o,
                                                            float* __restrict__ xn, int64_t hw4, int64_t total4,
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(256) void step_inpaint_kernel(const float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (rks[j] >= 0) x0h[j] = x0[j] - (x0[j] - yb[(int64_t)rks[j] * 3 + c]) * s.lambda;
-            st4(xn + base + c * hw4 * 4, update_of(x0h, ld4(noise + base + c * hw4 * 4), e, s));
+            st4(xn + base + c * hw4 * 4, update_of(x0h, nz4(noise, base + c * hw4 * 4), e, s));
         }
     }
 }
@@ -198,17 +218,17 @@ __global__ __launch_bounds__(256) void step_inpaint_kernel(const float* __restri
 extern "C" int ddnm_step_inpaint_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                                      const float* y, const int32_t* rank, int32_t n_kept, float* x0, float* xt_next,
                                      int32_t B, int32_t HW, const ddnm_step_scalars* s, void* stream) {
-    if (!xt || !et || !noise || !y || !rank || !xt_next || !s || B <= 0 || HW <= 0) return DDNM_E_BADARG;
+    if (!xt || !et || !y || !rank || !xt_next || !s || B <= 0 || HW <= 0 || !noise_ok(noise, s)) return DDNM_E_BADARG;
     if ((HW & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * HW / 4;
     DDNM_LAUNCH(step_inpaint_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
-                       noise, y, rank, n_kept, x0, xt_next, (int64_t)HW / 4, total4, *s);
+                       noise_src(noise, s, (int64_t)3 * HW), y, rank, n_kept, x0, xt_next, (int64_t)HW / 4, total4, *s);
     return 0;
 }
 
 // ---------------------------------------------------------------- fused: denoising (A = I)
 __global__ __launch_bounds__(256) void step_denoise_kernel(const float* __restrict__ xt, const float* __restrict__ et,
-                                                           int64_t et_bstride, const float* __restrict__ noise,
+                                                           int64_t et_bstride, NoiseSrc noise,
                                                            const float* __restrict__ y, float* __restrict__ x0o,
                                                            float* __restrict__ xn, int64_t chw4, int64_t total4,
                                                            ddnm_step_scalars s) {
@@ -218,18 +238,39 @@ __global__ __launch_bounds__(256) void step_denoise_kernel(const float* __restri
         const f32x4 x0 = x0_of(ld4(xt + i * 4), e, s);
         if (x0o) st4(x0o + i * 4, x0);
         const f32x4 x0h = x0 - (x0 - ld4(y + i * 4)) * s.lambda;
-        st4(xn + i * 4, update_of(x0h, ld4(noise + i * 4), e, s));
+        st4(xn + i * 4, update_of(x0h, nz4(noise, i * 4), e, s));
     }
 }
 
 extern "C" int ddnm_step_denoise_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise,
                                      const float* y, float* x0, float* xt_next, int32_t B, int64_t chw,
                                      const ddnm_step_scalars* s, void* stream) {
-    if (!xt || !et || !noise || !y || !xt_next || !s || B <= 0 || chw <= 0) return DDNM_E_BADARG;
+    if (!xt || !et || !y || !xt_next || !s || B <= 0 || chw <= 0 || !noise_ok(noise, s)) return DDNM_E_BADARG;
     if ((chw & 3) || (et_bstride & 3)) return DDNM_E_SHAPE;
     const int64_t total4 = (int64_t)B * chw / 4;
     DDNM_LAUNCH(step_denoise_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, xt, et, et_bstride,
-                       noise, y, x0, xt_next, chw / 4, total4, *s);
+                       noise_src(noise, s, chw), y, x0, xt_next, chw / 4, total4, *s);
+    return 0;
+}
+
+// ---------------------------------------------------------------- stand-alone Philox draw
+// out[b][r .. r+3] = philox_normal4(seed, r / 4, iter, img_base + b): exactly the values the step kernels draw in-kernel for
+// the same (seed, iteration, image); used for x_T, the time-travel re-noise, DDNM+ (whose Lambda_noise reads the tensor)
+__global__ __launch_bounds__(256) void randn_philox_kernel(float* __restrict__ out, int64_t chw4, int64_t total4, PhiloxKey key,
+                                                           unsigned iter, unsigned img_base) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / chw4, r = i - b * chw4;
+        st4(out + i * 4, philox_normal4(key, (unsigned)r, iter, img_base + (unsigned)b));
+    }
+}
+
+extern "C" int ddnm_randn_philox_f32(float* out, int32_t B, int64_t chw, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
+                                     uint32_t image_base, void* stream) {
+    if (!out || B <= 0 || chw <= 0) return DDNM_E_BADARG;
+    if (chw & 3) return DDNM_E_SHAPE;
+    const int64_t total4 = (int64_t)B * chw / 4;
+    DDNM_LAUNCH(randn_philox_kernel, GRID_1D(total4), dim3(256), 0, (hipStream_t)stream, out, chw / 4, total4,
+                PhiloxKey{seed_lo, seed_hi}, iter, image_base);
     return 0;
 }
 

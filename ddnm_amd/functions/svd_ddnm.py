@@ -18,8 +18,14 @@ hard-coded class 951 (:7,49-52); time travel re-noises the UN-projected x0
 prediction (:72-74).
 
 `noise` (optional) is an explicit tape: tensor [n_iters, B, 3, H, W] or a list of
-tensors, consumed one per loop iteration.  Without it, noise is drawn from the
-device generator like the reference's `torch.randn_like`.
+tensors, consumed one per loop iteration (the parity path).  Without it the
+N(0, I) draw of the reference's `torch.randn_like(x)` (svd_ddnm.py:65,74) happens
+INSIDE the step kernels (`ops.PhiloxNoise`: Philox4x32-10 + Box-Muller, counter =
+(element, iteration, global image index), key = the torch seed and a per-call
+counter): no noise tensor is written and read back, and no ATen kernel runs in
+the loop.  `noise=ops.PhiloxNoise(seed, image_base)` pins seed and the global
+index of the batch's first image (sharded runs); DDNM_NOISE=torch restores the
+ATen draw from the device generator.
 
 `return_cpu` (default True) matches the reference, which hands back CPU tensors
 (`xs[-1]`, `x0_preds[-1]` were `.to('cpu')`, svd_ddnm.py:67-68,76-78); the runner, the
@@ -218,10 +224,31 @@ class _GuidanceAhead:
             self.main.wait_stream(self.side)
 
 
+_PHILOX_CALLS = [0]
+
+
+def _philox_for_call(like):
+    """Key of an un-pinned run: the device generator's seed (torch.manual_seed / torch.cuda.manual_seed_all set it, like
+    the reference's main.py:139-143) and a per-call counter, so that consecutive restorations draw different noise."""
+    seed = torch.cuda.initial_seed() if like.is_cuda else torch.initial_seed()
+    _PHILOX_CALLS[0] += 1
+    return ops.PhiloxNoise((int(seed) & 0xFFFFFFFF) | ((_PHILOX_CALLS[0] & 0xFFFFFFFF) << 32))
+
+
 def _noise_source(noise, like):
-    if noise is None:
+    """draw(k) -> the noise tensor of loop iteration k, or None when the step kernels draw it themselves (`.philox`)."""
+    import os
+    if noise is None and os.environ.get("DDNM_NOISE") == "torch":
         def draw(k):
             return torch.randn_like(like)
+        draw.philox = None
+        return draw
+    if noise is None or isinstance(noise, ops.PhiloxNoise):
+        ph = _philox_for_call(like) if noise is None else noise
+
+        def draw(k):
+            return None
+        draw.philox = ph
         return draw
 
     def take(k):
@@ -229,6 +256,7 @@ def _noise_source(noise, like):
         if n.device != like.device or n.dtype != torch.float32 or not n.is_contiguous():
             n = n.to(device=like.device, dtype=torch.float32).contiguous()
         return n
+    take.philox = None
     return take
 
 
@@ -282,6 +310,8 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                 if et.size(1) == 6:
                     et = et[:, :3]
                 s = ops.step_scalars(at, at_next, eta)
+                if draw.philox is not None:
+                    draw.philox.stamp(s, k)          # the step kernel draws its own noise (noise pointer NULL)
                 if fused:
                     A_funcs.ddnm_step(xt, et, draw(k), y, s, x0_t, out)
                 else:          # foreign operator object: its own A / A_pinv, our elementwise kernels
@@ -291,7 +321,8 @@ def ddnm_diffusion(x, model, b, eta, A_funcs, y, cls_fn=None, classes=None, conf
                 have_x0 = True
             else:          # time-travel back (svd_ddnm.py:70-76)
                 assert have_x0
-                ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
+                nz = draw(k) if draw.philox is None else draw.philox.tensor(k, x0_t)
+                ops.renoise(x0_t, nz, float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
             if record is not None:
                 record(k, "x0_t", x0_t)
@@ -352,13 +383,15 @@ def ddnm_plus_diffusion(x, model, b, eta, A_funcs, y, sigma_y, cls_fn=None, clas
                 ops.step_x0(xt, et, s, out=x0_t)
                 resid = _axpby(A_funcs.A(x0_t), y, 1.0, -1.0)
                 corr = A_funcs.Lambda(A_funcs.A_pinv(resid), a, sigma_y, sigma_t, eta).reshape(x.shape)
-                nz = A_funcs.Lambda_noise(draw(k), a, sigma_y, sigma_t, eta, et).reshape(x.shape)
+                eps_k = draw(k) if draw.philox is None else draw.philox.tensor(k, x0_t)
+                nz = A_funcs.Lambda_noise(eps_k, a, sigma_y, sigma_t, eta, et).reshape(x.shape)
                 s.c1, s.c2, s.lam = 1.0, 0.0, 1.0        # x_t-1 = sqrt(abar') (x0 - corr) + 1 * nz
                 ops.step_combine(x0_t, corr, None, nz, et, s, out=out)
                 have_x0 = True
             else:
                 assert have_x0
-                ops.renoise(x0_t, draw(k), float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
+                nz = draw(k) if draw.philox is None else draw.philox.tensor(k, x0_t)
+                ops.renoise(x0_t, nz, float(at_next.sqrt()), float((1 - at_next).sqrt()), out=out)
             xt = out
             if record is not None:
                 record(k, "x0_t", x0_t)

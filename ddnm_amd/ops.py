@@ -765,6 +765,29 @@ def pack_conv_in_weight_im2col(w, cpad):
 
 
 # ----------------------------------------------------------------------------- sampler step
+class PhiloxNoise:
+    """In-kernel noise of one sampling run (include/ddnm_hip.h::ddnm_step_scalars::rng_*): instead of a tensor, the step
+    kernels get (seed, loop iteration, global index of the batch's first image) and draw N(0, I) themselves -- Philox4x32-10
+    + Box-Muller, counter = (element / 4, iteration, image), so the values do not depend on batch size or rank count.
+    `tensor(k, B, shape)` materialises the SAME values (x_T: iteration 0xFFFFFFFF; time-travel re-noise; DDNM+)."""
+    XT_ITER = 0xFFFFFFFF
+
+    def __init__(self, seed, image_base=0):
+        self.seed_lo, self.seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
+        self.image_base = int(image_base)
+
+    def stamp(self, s, k):
+        s.rng_on, s.rng_seed_lo, s.rng_seed_hi, s.rng_iter, s.rng_image_base = 1, self.seed_lo, self.seed_hi, int(k), self.image_base
+        return s
+
+    def tensor(self, k, like):
+        B = like.shape[0]
+        out = torch.empty(like.shape, dtype=torch.float32, device=like.device)
+        check(_lib.lib().ddnm_randn_philox_f32(_p(out), B, out.numel() // B, self.seed_lo, self.seed_hi, int(k) & 0xFFFFFFFF,
+                                               self.image_base, _stream()), "ddnm_randn_philox_f32")
+        return out
+
+
 def step_scalars(at, at_next, eta, lam=1.0, gamma=1.0):
     """Host-side scalar terms of one reverse step, evaluated in fp32 exactly like the reference
     (functions/svd_ddnm.py:57,63-65): `at`, `at_next` are fp32 torch scalars (alpha-bar)."""

@@ -422,7 +422,21 @@ typedef struct ddnm_step_scalars {
     float sqrt_at_next;   /* sqrt(alpha_bar_{t'}) */
     float c1, c2;         /* noise / eps mixing coefficients (already multiplied by gamma) */
     float lambda;         /* 1 for DDNM (sigma_y = 0) */
+    /* ABI 6 -- in-kernel noise: when a step entry point gets noise == NULL and rng_on != 0, the N(0, I) draw of
+     * `torch.randn_like(x)` (svd_ddnm.py:65) happens inside the kernel: Philox4x32-10 + Box-Muller with the counter
+     * (element / 4, rng_iter, rng_image_base + b, 0) and the key (rng_seed_lo, rng_seed_hi) -- no noise tensor is written
+     * or read, and an image's noise depends on its GLOBAL index only (rank-count independent sharding).
+     * ddnm_randn_philox_f32 produces the same values as a tensor. */
+    uint32_t rng_on;
+    uint32_t rng_seed_lo, rng_seed_hi;
+    uint32_t rng_iter;        /* loop iteration k */
+    uint32_t rng_image_base;  /* global index of image 0 of this launch */
+    uint32_t reserved_rng;
 } ddnm_step_scalars;
+
+/* out [B][chw] fp32 = the Philox draw described above (chw % 4 == 0) */
+int ddnm_randn_philox_f32(float* out, int32_t B, int64_t chw, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,
+                          uint32_t image_base, void* stream);
 
 /* x0 only (first half of every step; also feeds time travel). */
 int ddnm_step_x0_f32(const float* xt, const float* et, int64_t et_bstride, float* x0, int32_t B, int64_t chw,

@@ -52,7 +52,7 @@ def test_struct_layouts_match_header():
     assert ConvDesc.amax_in.offset == ctypes.sizeof(ConvDesc) - 8
     assert ConvDesc.workspace.offset == 9 * 8 + 16 * 4
     assert ctypes.sizeof(GemmDesc) == 4 * 8 + 10 * 4 + 8 * 8 + 2 * 4 + 2 * 4
-    assert ctypes.sizeof(StepScalars) == 24
+    assert ctypes.sizeof(StepScalars) == 24 + 6 * 4          # + the in-kernel noise fields of ABI 6
     src = open(HEADER).read()
     conv = src[src.index("typedef struct ddnm_conv_desc"):src.index("} ddnm_conv_desc;")]
     fields = re.findall(r"\b(?:const\s+)?(?:float|int32_t|int64_t)\s*\*?\s*([A-Za-z0-9_, ]+);", conv)
