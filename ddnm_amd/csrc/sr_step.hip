@@ -19,6 +19,18 @@
 
 constexpr int SR_D = 256, SR_M = 64, SR_BLK = 64;
 
+// the elementwise parts round like the other step kernels (ddnm_step.hip: mul / add separately, like the ATen kernels the
+// reference runs); only the four small matrix products below may contract into FMAs
+__device__ __forceinline__ f32x4 sr_x0_of(f32x4 xt, f32x4 et, const ddnm_step_scalars& s) {
+#pragma clang fp contract(off)
+    return (xt - et * s.sqrt_1m_at) / s.sqrt_at;
+}
+__device__ __forceinline__ f32x4 sr_update_of(f32x4 x0, f32x4 proj, f32x4 nz, f32x4 et, const ddnm_step_scalars& s) {
+#pragma clang fp contract(off)
+    const f32x4 x0h = x0 - proj * s.lambda;
+    return (x0h * s.sqrt_at_next + nz * s.c1) + et * s.c2;
+}
+
 struct SrNoise {
     const float* p;
     PhiloxKey key;
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(256) void sr_step_a_kernel(const float* __restrict_
     for (int e = tid; e < SR_D * (SR_BLK / 4); e += 256) {
         const int k = e / (SR_BLK / 4), q = e - k * (SR_BLK / 4);
         const size_t off = (size_t)k * SR_D + j0 + q * 4;
-        const f32x4 v = (*reinterpret_cast<const f32x4*>(xp + off) - *reinterpret_cast<const f32x4*>(ep + off) * s.sqrt_1m_at) / s.sqrt_at;
+        const f32x4 v = sr_x0_of(*reinterpret_cast<const f32x4*>(xp + off), *reinterpret_cast<const f32x4*>(ep + off), s);
         *reinterpret_cast<f32x4*>(x0p + off) = v;
         *reinterpret_cast<f32x4*>(Xb + k * SR_BLK + q * 4) = v;
     }
@@ -146,7 +158,6 @@ __global__ __launch_bounds__(256) void sr_step_b_kernel(const float* __restrict_
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t off = (size_t)(r0 + ti * 4 + r) * SR_D + tj * 16 + q * 4;
-            const f32x4 x0h = *reinterpret_cast<const f32x4*>(x0p + off) - pa[r][q] * s.lambda;
             f32x4 nz;
             if (noise.p) {
                 nz = *reinterpret_cast<const f32x4*>(noise.p + (size_t)plane * SR_D * SR_D + off);
@@ -154,7 +165,8 @@ __global__ __launch_bounds__(256) void sr_step_b_kernel(const float* __restrict_
                 const size_t in_img = (size_t)c * SR_D * SR_D + off;          // element offset inside image b
                 nz = philox_normal4(noise.key, (unsigned)(in_img >> 2), noise.iter, noise.img_base + (unsigned)b);
             }
-            *reinterpret_cast<f32x4*>(op + off) = (x0h * s.sqrt_at_next + nz * s.c1) + *reinterpret_cast<const f32x4*>(ep + off) * s.c2;
+            *reinterpret_cast<f32x4*>(op + off) = sr_update_of(*reinterpret_cast<const f32x4*>(x0p + off), pa[r][q], nz,
+                                                               *reinterpret_cast<const f32x4*>(ep + off), s);
         }
 }
 

@@ -878,8 +878,11 @@ class SRConv(A_functions):
         B = xt.shape[0]
         L = _lib.lib()
         need = L.ddnm_step_srconv_workspace_floats(B, self.channels, self.img_dim, self.small_dim)
-        if need > 0 and os.environ.get("DDNM_SR_STEP_GEMM") != "1":
-            # 256 x 256, 4x: the whole step in two launches (x0 + Ae X Ae^T partials | R, Pe R Pe^T, DDIM update)
+        if need > 0 and os.environ.get("DDNM_SR_STEP_FUSED") == "1":
+            # 256 x 256, 4x: the whole step in two launches (x0 + Ae X Ae^T partials | R, Pe R Pe^T, DDIM update).  Opt-in:
+            # measured against the six-launch route below (x0 kernel, four MFMA GEMMs, combine) on the headline workload it
+            # is 0.3 % SLOWER (5.969 / 5.951 vs 5.986 / 5.974 images/s, alternating runs on one box): 96 workgroups of fp32
+            # vector FMAs take as long as the launches they save (tools/experiments/HISTORY.md)
             if self._step_ws is None or self._step_ws.numel() < need:
                 self._step_ws = torch.empty(need, dtype=torch.float32, device=xt.device)
             ep, es = ops._et_args(et)
