@@ -679,12 +679,16 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
     // is used (once per 64-channel chunk), NOT kept in 11 registers across the MFMA loop: the accumulators (128), two
     // fragment sets (48) and the epilogue's residual tile leave no room (the first build spilled 34 registers); the empty
     // asm keeps the compiler from hoisting the arithmetic out of the chunk loop again.
+    // (row / HWd by multiply-shift: the runtime division costs ~35 vector instructions, and this lambda runs 22 times per
+    // chunk in a kernel whose K loop is 18 taps -- the first build spent 6.6 non-MFMA vector instructions per MFMA,
+    // profiles/r05_pmc_stalls_n128.md; exact for row < 2^20 / (magic * HWd - 2^20), i.e. far beyond the 344 rows here)
+    const unsigned hw_magic = (1u << 20) / (unsigned)HWd + 1u;
     auto halo_src = [&](int gi) -> int {
         int row = (wave + G::NWV * gi) * 8 + lrow;
         asm volatile("" : "+v"(row));
         int off = -1;
         if (row < NP) {
-            const int hy = row / HWd, hx = row - hy * HWd;
+            const int hy = (int)(((unsigned)row * hw_magic) >> 20), hx = row - hy * HWd;
             const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
             if ((unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W) {
                 const int sy = d.ups ? (iy >> 1) : iy, sx = d.ups ? (ix >> 1) : ix;
@@ -736,8 +740,16 @@ __global__ __launch_bounds__(256, 2) void conv16_n128_kernel(const Conv16Args p)
         gsc0 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4); gsc1 = *reinterpret_cast<const f32x4*>(Gb + lp8 * 4 + 16);
         gsh0 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4); gsh1 = *reinterpret_cast<const f32x4*>(Gb + 256 + lp8 * 4 + 16);
     };
+    // which of this lane's halo rows lie inside the image (bit gi): the same for every chunk, so one register instead of
+    // 11 offsets -- the GroupNorm pass below must leave the zero padding alone
+    unsigned in_image = 0u;
+    if (fuse_gn) {
+#pragma unroll
+        for (int gi = 0; gi < G::HG_PER_WAVE; ++gi)
+            if (wave + G::NWV * gi < G::HGROUPS && halo_src(gi) >= 0) in_image |= 1u << gi;
+    }
     auto act_group = [&](int gi) {
-        if (wave + G::NWV * gi < G::HGROUPS && halo_src(gi) >= 0) {
+        if (wave + G::NWV * gi < G::HGROUPS && ((in_image >> gi) & 1u)) {
             char* pl = Hb + (wave + G::NWV * gi) * 1024 + lane * 16;
             const half8 v = *reinterpret_cast<const half8*>(pl);
             f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
