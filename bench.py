@@ -159,7 +159,14 @@ def cpu_baseline(cfg, sd, budget_s=90.0):
     t_fwd = time.perf_counter() - t0
     n_steps = int(max(30, min(T_SAMPLING, budget_s // max(t_fwd, 1e-3))))
     dt = timed(1, n_steps)
+    cpu_model = "unknown"
+    try:                       # the figure swings 0.038 ... 0.054 images/s between boxes: name the host CPU next to it
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.lower().startswith("model name")), "unknown")
+    except OSError:
+        pass
     out = {"value": 1.0 / (dt / n_steps * T_SAMPLING), "unit": "images/sec", "cores": threads, "kind": kind,
+           "host_cpu": cpu_model, "logical_cpus": avail,
            "sample": f"B=1, {n_steps} of {T_SAMPLING} reverse steps timed ({dt:.1f} s) on {threads} threads ({avail} "
                      f"logical CPUs visible), extrapolated x{T_SAMPLING / n_steps:g}; `b8_value`: the workload's own batch "
                      "of 8 for 3 reverse steps, same extrapolation"}
