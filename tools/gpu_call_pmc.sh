@@ -16,7 +16,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/hbm/pmc_fetc
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/hbm/pmc_write -o p --output-format csv -- python /root/repo/tools/hbm_kernels.py 3 > /root/repo/gpurun_out/hbm_write.log 2>&1
 cd /root/repo
 R=${ROUND:-r05}
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true), false>' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM fp16 forwards at B=4 per pass (tools/adm_fwd.py)" python tools/pmc_stalls.py $RAW/adm gpurun_out/${R}_pmc_stalls_conv16.json gpurun_out/${R}_pmc_stalls_conv16.md
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_n128_kernel' PMC_PASSES="2 classifier-guidance evaluations at B=8 per pass (tools/cls_step.py)" python tools/pmc_stalls.py $RAW/cls gpurun_out/${R}_pmc_stalls_n128.json gpurun_out/${R}_pmc_stalls_n128.md
 python tools/pmc_hbm_summary.py $RAW/hbm gpurun_out/hbm_kernels_algorithmic.json gpurun_out/${R}_hbm_kernels.json gpurun_out/${R}_hbm_kernels.md
