@@ -100,6 +100,35 @@ def test_engine_classifier_fp16_operands(hip, kind, gen, golden_dir, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wscale,xscale", [(1.0, 1.0), (1.6, 3.0), (0.5, 0.3)])
+def test_fp16_activation_engine_tracks_the_fp32_engine_off_the_golden_point(hip, wscale, xscale):
+    """The fp16-activation engine against the engine's own fp32 path (itself <= 2e-4 from the reference's autograd) away from
+    the golden inputs: weights and inputs scaled up / down (activation and gradient magnitudes move by orders of magnitude
+    through the 2^10 gradient pre-scale), extreme timesteps, B = 5 (ragged against every tile size).  Finite everywhere,
+    gradient within the half-precision bar and aligned."""
+    cc = weights.classifier_config(**KINDS["mid"])
+    sd = {k: (v * wscale if v.dim() > 1 else v) for k, v in weights.classifier_state_dict(cc).items()}
+    g = torch.Generator().manual_seed(23)
+    r = cc.image_size
+    x = (torch.randn(5, 3, r, r, generator=g) * xscale).cuda()
+    t = torch.tensor([0.0, 999.0, 430.0, 10.0, 750.0]).cuda()
+    y = torch.tensor([951, 0, 999, 17, 500]).cuda()
+    ref = _engine(cc, sd)
+    want_l, want_g = ref(x, t).float().cpu(), ref.log_prob_grad(x, t, y).float().cpu()
+    m = _engine(cc, sd)
+    m.convert_to_fp16()
+    assert m.h16
+    got_l, got_g = m(x, t).float().cpu(), m.log_prob_grad(x, t, y).float().cpu()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got_l).all()) and bool(torch.isfinite(got_g).all())
+    assert rel(got_l, want_l) < 5e-3, rel(got_l, want_l)
+    for i in range(5):                                   # per image: one bad sample must not hide in the batch norm
+        e = rel(got_g[i], want_g[i])
+        cos = (got_g[i].double() * want_g[i].double()).sum() / (got_g[i].double().norm() * want_g[i].double().norm())
+        assert e < 2e-2 and cos > 0.9998, (i, e, float(cos))
+
+
+@pytest.mark.gpu
 def test_gn_backward_kernel(hip):
     """GroupNorm(+FiLM)+SiLU backward against torch autograd on CPU, incl. the half-resolution (avg-pool) mapping."""
     import torch.nn.functional as F
