@@ -186,7 +186,8 @@ class _GuidanceAhead:
             g = min(G, len(self.t_values) - self.pos)            # steps served by this pass
             m = g * self.n
             with torch.cuda.stream(self.side):
-                gg = self.cls_fn(self.xg[:m], self.tg[self.pos // G][:m], self.clsg[:m])
+                # (the engine's cond_fn is told that the batch is g copies of x: t-independent layers run once)
+                gg = self.cls_fn(self.xg[:m], self.tg[self.pos // G][:m], self.clsg[:m], replicas=g)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
             for j in range(g):

@@ -343,19 +343,25 @@ class EncoderUNetModel:
         col = ops.im2col16(x, None, gn, True)
         return ops.conv16(col, w16.reshape(w16.shape[0], 1, -1), cout, 1, **kw)
 
-    def _res_h16(self, n, L, x, film_all, tape):
+    def _res_h16(self, n, L, x, film_all, tape, shared=None):
         w = self.w
         cin, cout, mode = L[1], L[2], L[3]
         k1 = {} if tape is not None else None
         k2 = {} if tape is not None else None
-        gn1 = self._gn(x, n + ".in_layers.0", keep=k1)
         b1, b2 = w[n + ".in_layers.2.bias"], w[n + ".out_layers.3.bias"]
         xs = None
-        if mode == "down":          # AvgPool2d on both branches (unet.py:237-242)
+        if shared is not None:      # t-independent half of the block, evaluated once for the replicas of a grouped pass
+            h, k1s = shared
+            if k1 is not None:
+                k1.update(k1s)
+            xs = x.t
+        elif mode == "down":        # AvgPool2d on both branches (unet.py:237-242)
+            gn1 = self._gn(x, n + ".in_layers.0", keep=k1)
             hp = ops.gn_apply16(x, None, gn1, True, pool=True)
             xs = ops.gn_apply16(x, None, None, False, pool=True)
             h = self._conv3_16(n + ".in_layers.2.h16", cout, hp, None, bias=b1)
         else:
+            gn1 = self._gn(x, n + ".in_layers.0", keep=k1)
             h = self._conv3_16(n + ".in_layers.2.h16", cout, x, gn1, bias=b1)
             if cin == cout:
                 xs = x.t
@@ -392,22 +398,47 @@ class EncoderUNetModel:
             tape.append(("attn", n, x.t, qkv, o, lse, k))
         return out
 
-    def _forward_h16(self, x, film_all, tape):
-        """The torso on fp16 NHWC activations; returns the tensor the output head (GroupNorm, SiLU, pool) reads."""
+    def _forward_h16(self, x, film_all, tape, replicas=1):
+        """The torso on fp16 NHWC activations; returns the tensor the output head (GroupNorm, SiLU, pool) reads.
+
+        `replicas` = G > 1: the batch is G copies of the same B / G images with different timesteps (the grouped guidance
+        pass of svd_ddnm.py::_GuidanceAhead).  The input convolution and the first ResBlock's `in_layers` (GroupNorm, SiLU,
+        3x3 convolution) do not see the timestep -- FiLM enters at `out_layers` (unet.py:248-251) -- so they are evaluated
+        ONCE on the B / G distinct images and their results (tensor, GroupNorm partials, kept affine) replicated; every
+        launch computes a pixel tile from its own image only, so this is bit-identical to evaluating all G copies."""
         w = self.w
         n0 = "input_blocks.0.0"
-        h = ops.nchw_to_nhwc16(x.float().contiguous(), 64)
-        h = ops.conv16(h, w[n0 + ".h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
+        B = x.shape[0]
+        first = self.input_blocks[1][0] if len(self.input_blocks) > 1 else None
+        share = (replicas > 1 and B % replicas == 0 and first is not None and first[0] == "res" and first[3] == ""
+                 and first[1] == first[2] and os.environ.get("DDNM_CLS_SHARE_PREFIX") != "0")
+        shared = None
+        if share:
+            G, nu = replicas, B // replicas
+            rep = lambda t_: torch.cat([t_] * G, 0)           # noqa: E731
+            hu = ops.nchw_to_nhwc16(x[:nu].float().contiguous(), 64)
+            hu = ops.conv16(hu, w[n0 + ".h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
+            n1 = "input_blocks.1.0"
+            k1u = {}
+            gn1 = self._gn(hu, n1 + ".in_layers.0", keep=k1u)
+            au = self._conv3_16(n1 + ".in_layers.2.h16", first[2], hu, gn1, bias=w[n1 + ".in_layers.2.bias"])
+            h = ops.Act(rep(hu.t), None if hu.stats is None else rep(hu.stats), hu.tiles)
+            a1 = ops.Act(rep(au.t), None if au.stats is None else rep(au.stats), au.tiles)
+            k1 = {k: (rep(v) if torch.is_tensor(v) else v) for k, v in k1u.items()}
+            shared = (a1, k1)
+        else:
+            h = ops.nchw_to_nhwc16(x.float().contiguous(), 64)
+            h = ops.conv16(h, w[n0 + ".h16"], self.input_blocks[0][0][2], 3, bias=w[n0 + ".bias"])
         for prefix, layers in self._walk():
             for j, Ld in enumerate(layers):
                 n = f"{prefix}.{j}"
                 if Ld[0] == "res":
-                    h = self._res_h16(n, Ld, h, film_all, tape)
+                    h = self._res_h16(n, Ld, h, film_all, tape, shared=shared if n == "input_blocks.1.0" else None)
                 elif Ld[0] == "attn":
                     h = self._attn_h16(n, h, tape)
         return h
 
-    def forward(self, x, timesteps, tape=None):
+    def forward(self, x, timesteps, tape=None, replicas=1):
         """logits [B, 1000]; with `tape` (a list) the activations needed by the backward pass are recorded."""
         if self.w is None:
             raise RuntimeError("load_state_dict() must be called before forward()")
@@ -425,7 +456,7 @@ class EncoderUNetModel:
         emb = ops.linear(emb, w["time_embed.2.weight"], w["time_embed.2.bias"], silu_in=True)
         film_all = ops.linear(emb, w["film_cat.weight"], w["film_cat.bias"], silu_in=True)
         if self.use_fp16 and self.h16:
-            h = self._forward_h16(x, film_all, tape)
+            h = self._forward_h16(x, film_all, tape, replicas)
             return self._head(h, x, tape)
         im2col = "input_blocks.0.0.weight.im2col" in w
         h = (ops.nchw_im2col3x3_pad if im2col else ops.nchw_to_nhwc_pad)(x.float().contiguous(), CIN_PAD)
@@ -556,8 +587,9 @@ class EncoderUNetModel:
         dn = ops.conv16(dqkv, w[n + ".qkv.dgrad.h16"], C, 1, emit_stats=False).t
         return self._gn_bwd16(x, dn, k, False, add=dout)
 
-    def log_prob_grad(self, x, timesteps, y):
-        """d/dx log_softmax(classifier(x, t))[y]  as NCHW [B, 3, R, R]."""
+    def log_prob_grad(self, x, timesteps, y, replicas=1):
+        """d/dx log_softmax(classifier(x, t))[y]  as NCHW [B, 3, R, R].  `replicas` = G: the caller asserts that x is G
+        copies of the same B / G images (see `_forward_h16`); results do not depend on it."""
         L = _lib.lib()
         w = self.w
         B = x.shape[0]
@@ -565,7 +597,7 @@ class EncoderUNetModel:
         if B > mb:                   # micro-batches: forward + backward per chunk, gradients concatenated
             return torch.cat([self.log_prob_grad(x[i:i + mb], timesteps[i:i + mb], y[i:i + mb]) for i in range(0, B, mb)], 0)
         tape = []
-        logits = self.forward(x, timesteps, tape=tape)
+        logits = self.forward(x, timesteps, tape=tape, replicas=replicas)
         yy = y.to(device=x.device, dtype=torch.int64).contiguous().view(-1)
         dlogits = torch.empty_like(logits)
         check(L.ddnm_logsoftmax_grad_f32(_p(logits), _p(yy), _p(dlogits), B, logits.shape[1], ops._stream()),
@@ -613,8 +645,8 @@ class EncoderUNetModel:
 def make_cond_fn(classifier, classifier_scale):
     """The `cond_fn` closure of guided_diffusion/diffusion.py:183-189 on the HIP engine."""
 
-    def cond_fn(x, t, y):
-        g = classifier.log_prob_grad(x, t, y)
+    def cond_fn(x, t, y, replicas=1):
+        g = classifier.log_prob_grad(x, t, y, replicas=replicas)
         if classifier_scale != 1.0:
             from ..functions.svd_operators import _axpby
             g = _axpby(g, None, float(classifier_scale), 0.0)

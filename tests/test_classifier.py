@@ -129,6 +129,34 @@ def test_fp16_activation_engine_tracks_the_fp32_engine_off_the_golden_point(hip,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,G", [("mid", 3, 4), ("full", 2, 3)])
+def test_grouped_pass_shares_the_timestep_independent_prefix(hip, monkeypatch, kind, n, G):
+    """A grouped guidance pass is G copies of the same n images with G timesteps (svd_ddnm.py::_GuidanceAhead).  The input
+    convolution and the first ResBlock's in_layers do not see the timestep, so the fp16-activation engine evaluates them once
+    for the n distinct images (`replicas=G`) -- bit-identical to evaluating every copy (DDNM_CLS_SHARE_PREFIX=0), and each
+    copy equals the un-grouped call at its own timestep."""
+    from ddnm_amd.guided_diffusion.classifier import make_cond_fn
+    cc = weights.classifier_config(**KINDS[kind])
+    m = _engine(cc, weights.classifier_state_dict(cc))
+    m.convert_to_fp16()
+    fn = make_cond_fn(m, 1.0)
+    g = torch.Generator().manual_seed(5)
+    r = cc.image_size
+    x = torch.randn(n, 3, r, r, generator=g).cuda()
+    xg = torch.cat([x] * G, 0)
+    tg = torch.tensor([float(10 + 240 * k) for k in range(G) for _ in range(n)]).cuda()
+    yg = torch.full((G * n,), 951).cuda()
+    shared = fn(xg, tg, yg, replicas=G)
+    monkeypatch.setenv("DDNM_CLS_SHARE_PREFIX", "0")
+    plain = fn(xg, tg, yg, replicas=G)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(shared).all()) and torch.equal(shared, plain)
+    assert torch.equal(shared, fn(xg, tg, yg))
+    one = fn(x, tg[n:2 * n].contiguous(), yg[:n])              # the second timestep alone: other launch plans (batch n)
+    assert rel(shared[n:2 * n], one) < 5e-3
+
+
+@pytest.mark.gpu
 def test_gn_backward_kernel(hip):
     """GroupNorm(+FiLM)+SiLU backward against torch autograd on CPU, incl. the half-resolution (avg-pool) mapping."""
     import torch.nn.functional as F
