@@ -75,5 +75,13 @@ PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PAS
 cp gpurun_out/${R}_adm_pmc_conv16_b8.json gpurun_out/${R}_adm_pmc_conv16_b8.md profiles/
 # bench.py reports HBM traffic / MFMA-busy only from a PMC summary stamped with the digest of the library it loads
 # (profiles/*_pmc_dominant_kernel.json, profiles/*_adm_pmc_conv16.json): install this run's summaries first
+# the stall table of the headline kernel travels inside its PMC file as well (`stall_attribution`)
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${R}_pmc_dominant_kernel.json")); st = json.load(open("gpurun_out/${R}_pmc_stalls_headline.json"))
+if d.get("source_digest") == st.get("source_digest"):
+    d["stall_attribution"] = {"source": "profiles/${R}_pmc_stalls_headline.json", "units": st["units"], "all_launches": st["all_launches"], "by_grid": st["by_grid"]}
+    json.dump(d, open("gpurun_out/${R}_pmc_dominant_kernel.json", "w"), indent=1)
+PY
 cp gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md profiles/
 timeout 1200 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/${R}_bench_line.json 2> gpurun_out/bench.log; cat gpurun_out/${R}_bench_line.json
