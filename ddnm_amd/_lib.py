@@ -29,7 +29,7 @@ class ConvDesc(Structure):
         ("stats_out", c_void_p),
         ("skip0", c_void_p), ("skip1", c_void_p), ("skip_weight", c_void_p),
         ("SC0", c_int32), ("SC1", c_int32),
-        ("acc_scale", c_float), ("reserved0", c_int32),
+        ("acc_scale", c_float), ("flags", c_int32),
         ("amax_in", c_void_p),
     ]
 

@@ -28,6 +28,10 @@ static inline bool conv_sizes_addressable(const ddnm_conv_desc* d) {
     return out_el < lim && src_b < lim && w_b < lim && sk_el < lim;
 }
 
+// persistent form of the split-fp16 3x3 kernel (conv_s16_persist.hip), dispatched from conv_igemm_f16.hip::run_f16
+bool conv3x3_s16_persist_eligible(const ConvArgs& p);
+int conv3x3_s16_persist_launch(const ConvArgs& p, hipStream_t s);
+
 // ---- tile geometry helper: local row r of M-tile -> output pixel
 struct TileMap {
     int img, ty0, tx0, th_unused, TW, TW_log2, flat_base, Wo;
@@ -122,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
                     if (partial) ws[o[i][j][r]] = v;
                     else out[o[i][j][r]] = v;
                     cs[j] += v;
-                    cq[j] += v * v;
+                    cq[j] = __builtin_fmaf(v, v, cq[j]);      // explicit: every kernel that shares this epilogue (and conv_s16_persist.hip) rounds alike
                 }
         }
     } else {
@@ -179,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
                 else out[o[r]] = v;
                 }
                 cs[j] += v;
-                cq[j] += v * v;
+                cq[j] = __builtin_fmaf(v, v, cq[j]);      // explicit: every kernel that shares this epilogue (and conv_s16_persist.hip) rounds alike
             }
             // 128 x 64 wave tiles (8 accumulator tiles live): keep the scheduler from interleaving the loads / stores of
             // several tiles, which pushed the 4-wave split kernel over its 256-register budget (8 spilled registers)

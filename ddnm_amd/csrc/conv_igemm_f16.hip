@@ -22,21 +22,12 @@
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Build-time tile variants for probing (tools/conv16_ablate.py): -DDDNM_F16_KC=32 -DDDNM_F16_BM=512 is the 8-wave
-// 512x128 block with 128x64 wave tiles (25 % fewer LDS fragment reads per MFMA); defaults = the production tile.
-#ifndef DDNM_F16_KC
-#define DDNM_F16_KC 64
-#endif
-#ifndef DDNM_F16_BM
-#define DDNM_F16_BM 256
-#endif
-#ifndef DDNM_F16_KS_TARGET
-#define DDNM_F16_KS_TARGET 256      // split-K: workgroups a low-resolution launch is spread over.  ONE workgroup fits a CU
+constexpr int KC16 = 64;            // halfs per LDS row of one chunk
+constexpr int F16_BM = 256;         // pixels per block tile
+constexpr int F16_KS_TARGET = 256;  // split-K: workgroups a low-resolution launch is spread over.  ONE workgroup fits a CU
                                     // (151 KB of LDS), so 256 = a single round; 512 (the fp32 kernel's figure, two
                                     // workgroups per CU) doubles the fp32 slab traffic for nothing: 32^2 / 16^2 layers
-                                    // of the celeba UNet at B = 8 run 12-29 % faster with 256 (tools/s16_probe.py)
-#endif
-constexpr int KC16 = DDNM_F16_KC;   // channels per chunk
+                                    // of the celeba UNet at B = 8 run 12-29 % faster with 256
 constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 
 // SRC16 = the activation operand is already fp16 in HBM (written by ddnm_gn_apply_f16: GroupNorm affine +
@@ -55,19 +46,10 @@ constexpr int LDH = KC16 + 8;       // LDS row pitch in halfs (144 B)
 // operand of a launch without GroupNorm (Upsample convolution) and the fused shortcut's input -- are multiplied by a
 // per-launch, per-image power of two while they are split, and the accumulator by its inverse (conv_common.h::
 // s16_operand_scale).  Launches whose operands are all GroupNorm'd run the ASCALE = false instance (no multiply).
-//
-// W4 (round 5; split form, <2, 2, 4, 2, ...>: FOUR waves, wave tile 128 x 64, the same 256 x 128 block) = TWO workgroups
-// per CU.  The counter-level attribution of the 8-wave form (profiles/r05_pmc_stalls_headline.md) books 37 % of all wave
-// cycles as parked at s_waitcnt / s_barrier -- with one workgroup per CU every wave of the CU parks at the SAME barrier,
-// so that time is lost on the matrix pipe (MFMA-busy 0.52) -- and 40 % as issue stalls behind the other wave's MFMAs.
-// Two independent workgroups per CU de-phase: one's barriers, chunk hand-overs and epilogue run under the other's MFMAs,
-// and the 128 x 64 wave tile needs 6 instead of 8 fragment reads per 8 MFMA triples.  To fit 2 x 80 KB of LDS the halo has
-// ONE buffer (re-staged between chunks behind a barrier: the other workgroup covers the gap) and the weights two.
-template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false, bool ASCALE = false, bool W4 = false>
-__global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_kernel(const ConvArgs p) {
+template <int WM, int WN, int MT, int NT, bool SRC16, bool SPLIT = false, bool ASCALE = false>
+__global__ __launch_bounds__(WM * WN * 64, 1) void conv3x3_halo_f16_kernel(const ConvArgs p) {
     static_assert(!(SPLIT && SRC16), "the split form reads fp32 activations");
     static_assert(SPLIT || !ASCALE, "operand scaling belongs to the split form");
-    static_assert(!W4 || (SPLIT && WM * WN == 4), "the two-workgroups-per-CU form is the 4-wave split kernel");
     constexpr int NTHREADS = WM * WN * 64;
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr int MAXH = BM == 512 ? 612 : (BM == 256 ? 340 : (BM == 128 ? 204 : 136));
@@ -82,17 +64,14 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
     constexpr int BROWS_PER_PASS = NTHREADS / BCOLS;
     constexpr int BR = BN / BROWS_PER_PASS;                       // LDS-DMA instructions per wave and weight tile
     static_assert(BR >= 1 && BN % BROWS_PER_PASS == 0, "weight tile / thread mapping");
-    constexpr int NWB = W4 ? 2 : 3;                               // weight tiles in LDS (tap, tap+1, tap+2; W4: tap, tap+1)
+    constexpr int NWB = 3;                                        // weight tiles in LDS (tap, tap+1, tap+2)
     constexpr int WTILE = BN * 128;                               // bytes of one weight tile
-    constexpr int HBYTES = (W4 ? 1 : 2) * MAXH * LDH * 2;         // halo, double-buffered (see main loop; W4: one buffer)
-    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read).
-    // W4: 2 x 16 KB + 48960 B = 81728 B, two workgroups per CU; the statistics scratch of the epilogue aliases the weight
-    // buffers (conv_epilogue synchronises before it writes them)
-    __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + HBYTES + (W4 ? 0 : WM * BN * 2 * 4)];
-    static_assert(!W4 || 2 * sizeof(lds_all) <= 160 * 1024, "two workgroups per CU");
+    constexpr int HBYTES = 2 * MAXH * LDH * 2;                    // halo, double-buffered (see main loop)
+    // ONE shared object (a second one makes the compiler drain the LDS-DMA queue in front of every fragment read)
+    __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + HBYTES + WM * BN * 2 * 4];
     char* const Bs = lds_all;
     _Float16* const Hs = reinterpret_cast<_Float16*>(lds_all + NWB * WTILE);
-    float* const stat_lds = reinterpret_cast<float*>(lds_all + (W4 ? 0 : NWB * WTILE + HBYTES));
+    float* const stat_lds = reinterpret_cast<float*>(lds_all + NWB * WTILE + HBYTES);
 
     const ddnm_conv_desc& d = p.d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,14 +113,12 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
         const_cast<void*>(reinterpret_cast<const void*>(d.weight)), 0, (unsigned)p.n_tiles * BN * w_rowlen, 0x00020000);
     const unsigned w_voff = (unsigned)(n_tile * BN + wave * 8 + lrow) * w_rowlen + (unsigned)((lpiece ^ wswz) * 16);
     auto issue_w = [&](int chunk, int tap, int buf) {
-#ifndef DDNM_PROBE16_NO_BLOAD
         char* dst = Bs + buf * WTILE + wave * 1024;
         const unsigned so = ((unsigned)tap * p.Cin + (unsigned)chunk * KCH) * WE * 2u;
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (__attribute__((address_space(3))) void*)(dst + j * (NTHREADS / 64) * 1024),
                                                      16, w_voff, so + (unsigned)j * (NTHREADS / 8) * w_rowlen, 0, 0);
-#endif
     };
     // register-staged weights (fused shortcut only): thread -> (16-byte column c8 of 8, rows brow + BROWS_PER_PASS*i)
     const int c8 = tid % BCOLS, brow = tid / BCOLS;
@@ -207,9 +184,7 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
                     *reinterpret_cast<uint4*>(dst) = h_st[i];
                 } else {
                     f32x4 v = __builtin_bit_cast(f32x4, h_st[i]);
-#ifndef DDNM_PROBE_NO_GN              // timing probe (wrong results): no GroupNorm affine / swish in the loader
                     if (has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
-#endif
                     if constexpr (SPLIT && ASCALE) {
                         split_store(dst, v, ascale);
                     } else if constexpr (SPLIT) {
@@ -313,46 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
     // competing for the matrix pipe in phase, the low-priority wave fills the other's barrier / fragment-read gaps.
     // Split form: +2.4 ... 2.9 % on the 256^2 layers, nothing elsewhere (tools/s16_probe.py vtime base prio_half); no
     // effect was ever measured for the fp16-operand form, which keeps the default.
-#ifndef DDNM_PROBE_NO_SETPRIO
     if (SPLIT && wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: the same for every form
-    if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
-#endif
-    if constexpr (W4) {
-        // ---- two workgroups per CU: plain loop, every wait a full one (the other workgroup fills the gaps).
-        // [weights(tap) landed + halo writes visible | barrier | request weights(tap + 1) | MFMA(tap)]; between chunks:
-        // barrier (the halo is free) -> load, GroupNorm / swish / split, write the next chunk's halo.
-        if (c_begin < c_end) {
-            prefetch_halo(c_begin);
-            issue_w(c_begin, 0, 0);
-            stage_halo_part(0, 0, HR);
-            int wbuf = 0;
-            for (int chunk = c_begin; chunk < c_end; ++chunk) {
-                const bool more = chunk + 1 < c_end;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    if (tap + 1 < 9) issue_w(chunk, tap + 1, wbuf ^ 1);
-                    else if (more) issue_w(chunk + 1, 0, wbuf ^ 1);
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfma_tap(tap, wbuf, 0);
-                    wbuf ^= 1;
-                }
-                if (more) {
-                    __builtin_amdgcn_s_barrier();          // every wave has finished this chunk's fragment reads
-                    asm volatile("" ::: "memory");
-                    prefetch_halo(chunk + 1);
-                    stage_halo_part(0, 0, HR);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    } else
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         const int last_step = (c_end - c_begin) * 9 - 1;
@@ -389,10 +325,8 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BR) : "memory");
                 }
-#ifndef DDNM_PROBE16_NO_TAP_BARRIER
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-#endif
                 issue_step(step + 2, cur >= 1 ? cur - 1 : NWB - 1);     // (step + 2) % 3: the buffer W(step - 1) just left
                 // pin the issue order the counted waits assume: this tap's DMA requests first, then its halo requests
                 // (the scheduler may not move anything across; the compiler barrier keeps IR passes from sinking the loads)
@@ -407,18 +341,10 @@ __global__ __launch_bounds__(WM * WN * 64, W4 ? 2 : 1) void conv3x3_halo_f16_ker
                     prefetch_halo_part(nchunk, HSPLIT, HR, more);
                 }
                 if (tap == 6 && more) stage_halo_part(hb ^ 1, HSPLIT, HR);
-#ifndef DDNM_PROBE16_NO_SCHED_BARRIER
                 // keep the requests issued above in front of this tap's MFMAs: left alone, the scheduler sinks
                 // them behind the MFMAs (VGPR pressure) and their latency lands on the barrier of every tap
                 __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef DDNM_PROBE_SETPRIO_MFMA      // probe: the MFMA burst of a tap at raised wave priority
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 mfma_tap(tap, cur, hb);
-#ifdef DDNM_PROBE_SETPRIO_MFMA
-                __builtin_amdgcn_s_setprio(0);
-#endif
             }
             hb ^= 1;
         }
@@ -504,7 +430,7 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl, int kch = KC16) {
         const int64_t cmax = d->C0 > d->C1 ? d->C0 : d->C1;
         if (px * cmax * (d->src_f16 ? 2 : 4) >= (int64_t)1 << 31) return false;
     }
-    pl->BM = DDNM_F16_BM;
+    pl->BM = F16_BM;
     if (HWo % pl->BM) return false;
     int tw = 32;
     while (tw > 8 && (d->Wo % tw || d->Ho % (pl->BM / tw))) tw >>= 1;
@@ -516,7 +442,7 @@ static bool plan_f16(const ddnm_conv_desc* d, PlanF16* pl, int kch = KC16) {
     int ks = 1;
     const int nchunks = Cin / kch;
     if (tiles < 192) {
-        ks = (int)((DDNM_F16_KS_TARGET + tiles - 1) / tiles);
+        ks = (int)((F16_KS_TARGET + tiles - 1) / tiles);
         if (ks > nchunks) ks = nchunks;
         if (ks > 16) ks = 16;
     }
@@ -541,23 +467,12 @@ extern "C" int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d) {
     return pl.ksplit > 1 ? splitk_stats_tiles(d) : d->Ho * d->Wo / pl.BM;
 }
 
-// DDNM_S16_UNGUARDED=1 (probes / A-B timing only): accept raw-operand split launches without an operand bound
-static bool s16_unguarded_ok() {
-    static const bool ok = [] { const char* e = getenv("DDNM_S16_UNGUARDED"); return e && e[0] == '1'; }();
-    return ok;
-}
-
-static bool s16_w4_enabled() {
-    static const bool on = [] { const char* e = getenv("DDNM_S16_W4"); return e && e[0] == '1'; }();
-    return on;
-}
-
 static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     const int kch = split ? KC16 / 2 : KC16;
     if (!d || !d->src0 || !d->weight || !d->out) return DDNM_E_BADARG;
     if (split && (d->src_f16 || !(d->acc_scale > 0.f))) return DDNM_E_BADARG;
     // raw operands (no GroupNorm in front of the main operand, or a fused shortcut) need the operand bound: fp16 range
-    if (split && !d->amax_in && (!d->gn_scale || d->skip0) && !s16_unguarded_ok()) return DDNM_E_BADARG;
+    if (split && !d->amax_in && (!d->gn_scale || d->skip0)) return DDNM_E_BADARG;
     if (d->B <= 0 || d->Cout <= 0 || d->Ho <= 0 || d->Wo <= 0) return DDNM_E_BADARG;
     if (!conv_sizes_addressable(d)) return DDNM_E_SHAPE;
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
@@ -592,26 +507,14 @@ static int run_f16(const ddnm_conv_desc* d, void* stream, bool split) {
     p.ksplit = pl.ksplit;
     p.ws = d->workspace;
     hipStream_t s = (hipStream_t)stream;
+    // launches of >= 2 tiles per CU: the persistent form (conv_s16_persist.hip; bit-identical results), unless the caller
+    // asks for the one-tile kernel (ddnm_conv_desc::flags & DDNM_CONV_ONE_TILE: A/B timing and the bit-identity tests)
+    if (split && !(d->flags & DDNM_CONV_ONE_TILE) && conv3x3_s16_persist_eligible(p)) return conv3x3_s16_persist_launch(p, s);
     const dim3 grid(p.m_tiles * p.n_tiles, pl.ksplit);
-#if DDNM_F16_BM == 512         // probe: 8 waves with 128x64 wave tiles over a 512-pixel patch
-    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 4, 2, true>), grid, dim3(512), 0, s, p); }
-    else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 4, 2, false>), grid, dim3(512), 0, s, p); }
-#elif defined(DDNM_F16_WAVE128)  // probe: 4 waves with 128x64 wave tiles (1 wave per SIMD)
-    if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, true>), grid, dim3(256), 0, s, p); }
-    else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false>), grid, dim3(256), 0, s, p); }
-#else
-    // DDNM_S16_W4=1 (A/B switch, off by default): split launches with at least two workgroups per CU and no split-K run
-    // the 4-wave kernel, two workgroups per CU.  Measured equal to the 8-wave kernel within +-3 % on every 256^2 / 128^2
-    // layer shape (tools/s16_probe.py time, same box): the launches are power-limited, see DESIGN.md section 3.0
-    if (split && pl.ksplit == 1 && (long)p.m_tiles * p.n_tiles >= 512 && s16_w4_enabled()) {
-        if (d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, true, true>), grid, dim3(256), 0, s, p); }
-        else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<2, 2, 4, 2, false, true, false, true>), grid, dim3(256), 0, s, p); }
-    } else
     if (split && d->amax_in) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, true>), grid, dim3(512), 0, s, p); }
     else if (split) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true>), grid, dim3(512), 0, s, p); }
     else if (d->src_f16) { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, true>), grid, dim3(512), 0, s, p); }
     else { DDNM_LAUNCH((conv3x3_halo_f16_kernel<4, 2, 2, 2, false>), grid, dim3(512), 0, s, p); }
-#endif
     if (pl.ksplit > 1) return launch_splitk_reduce(p, s);
     return 0;
 }

@@ -92,7 +92,8 @@ def pack_conv_weight(w, cin_pad=None):
 
 
 import os as _os
-_NO_FUSED_GN = _os.environ.get("DDNM_NO_FUSED_GN") == "1"      # A/B switch for profiling
+_NO_FUSED_GN = False      # module attribute (A/B profiling from a script): convolutions emit no GroupNorm partials
+FORCE_ONE_TILE = False    # module attribute (A/B timing from a script): every split-fp16 3x3 launch on the one-tile kernel
 
 
 class Act:
@@ -170,7 +171,7 @@ def conv_runs_s16_gather(B, H, W, cin, cout, ksize=3, stride=1):
 
 
 _S16_ACT_SCALE = None
-_NO_S16_GATHER = _os.environ.get("DDNM_NO_S16_GATHER") == "1"      # A/B switch: gather-form launches stay on the fp32 MFMA kernel
+_NO_S16_GATHER = False      # module attribute (A/B from a script): gather-form launches stay on the fp32 MFMA kernel
 
 
 def _s16_act_scale():
@@ -189,7 +190,7 @@ def conv_runs_f16(B, H, W, cin, cout, ksize=3):
     return (L.ddnm_conv3x3_f16_supported if ksize == 3 else L.ddnm_conv1x1_f16_supported)(ctypes.byref(d)) == 1
 
 
-_F16_PREPASS_MIN_COUT = int(_os.environ.get("DDNM_F16_PREPASS_MIN_COUT", "256"))
+_F16_PREPASS_MIN_COUT = 256
 _f16_scratch_buf = {}
 
 
@@ -232,8 +233,10 @@ def amax_bound(a0, a1=None):
 def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_stride=0, res=None, res_ups=False,
            gn=None, gn_silu=True, stride=1, pad=None, ups=False, out=None, out_nchw=False, out_hw=None, tile=0,
            emit_stats=False, weight_f16=None, skip=None, skip_weight=None, skip_weight_f16=None, weight_s16=None,
-           raw_amax=None):
+           raw_amax=None, one_tile=False):
     """NHWC implicit-GEMM convolution; see include/ddnm_hip.h::ddnm_conv_desc.
+    one_tile=True: the split-fp16 3x3 launch runs the one-tile-per-workgroup kernel where the persistent form would apply
+    (same results bit for bit; A/B timing and the bit-identity tests).
     With emit_stats=True returns an `Act` (tensor + GroupNorm partials when the launch can produce them).
     weight_s16 = (packed, scale, packed_skip or None) from pack_conv_weight_s16: 3x3 / stride-1 launches whose shape
     qualifies then run the split-fp16 kernel (fp32-grade products on the fp16 matrix pipe) instead of the fp32 one.
@@ -265,6 +268,7 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
     d.ksize, d.stride, d.pad, d.Ho, d.Wo = ksize, stride, pad, Ho, Wo
     d.ups, d.gn_silu, d.out_nchw = int(ups), int(gn_silu), int(out_nchw)
     d.badd_stride, d.tile, d.res_ups = badd_stride, tile, int(res_ups)
+    d.flags = 1 if (one_tile or FORCE_ONE_TILE) else 0
     L = _lib.lib()
     if out_nchw and cout <= 4 and skip is None and weight_f16 is None and L.ddnm_conv3x3_small_cout_f32_supported(ctypes.byref(d)) == 1:
         # the network's 3-channel output convolution: HBM-bound vector-ALU kernel (csrc/conv_small_f32.hip)

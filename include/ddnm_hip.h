@@ -88,7 +88,8 @@ typedef struct ddnm_conv_desc {
     int32_t SC0, SC1;
     float acc_scale;        /* ddnm_conv3x3_s16_f32 only: power of two that multiplies the accumulator before bias / residual
                                (undoes the operand pre-scaling of the split form); ignored by the other entry points */
-    int32_t reserved0;
+    int32_t flags;          /* bit 0 (DDNM_CONV_ONE_TILE): ddnm_conv3x3_s16_f32 runs the one-tile-per-workgroup kernel even where
+                               the persistent form (>= 2 tiles per CU) applies -- same results bit for bit; for A/B timing */
     /* ABI 5 -- operand-range guard of the split forms (ddnm_conv3x3_s16_f32, ddnm_conv_gather_s16_f32; ignored by every
      * other entry point).  fp16 carries |v| < 65504 only, fp32 -- the arithmetic the reference runs -- does not care, so
      * operands the kernel reads RAW (no GroupNorm in front: src0 / src1 when gn_scale is NULL, skip0 / skip1 always) are
@@ -103,6 +104,7 @@ typedef struct ddnm_conv_desc {
     const float* amax_in;
 } ddnm_conv_desc;
 
+#define DDNM_CONV_ONE_TILE 1
 #define DDNM_AMAX_N 32   /* bound words per image (= the GroupNorm group count of both networks) */
 
 int ddnm_conv2d_f32(const ddnm_conv_desc* d, void* stream);
