@@ -197,9 +197,6 @@ PROTOTYPES = {
                                        c_int32, c_void_p]),
     "ddnm_mul_planes_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
     "ddnm_fill_f32": (c_int32, [c_void_p, c_int64, c_float, c_void_p]),
-    "ddnm_step_srconv_workspace_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
-    "ddnm_step_srconv_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(StepScalars), c_void_p]),
     "ddnm_randn_philox_f32": (c_int32, [c_void_p, c_int32, c_int64, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
@@ -223,7 +220,7 @@ class DDNMHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def lib():

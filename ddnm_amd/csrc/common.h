@@ -34,11 +34,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 
 // swish with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_f(float v) {
-#ifdef DDNM_PROBE_SLOW_SILU
-    return v / (1.0f + __expf(-v));
-#else
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
-#endif
 }
 
 // 32x32 MFMA tile step over 8 k-values held as two float4 (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7)

@@ -21,7 +21,6 @@
 // next tap is requested right after the barrier that frees its buffer -- one barrier per 32 MFMAs per wave.
 // 1x1 convolutions / the im2col'ed 8x8 level run the same loop with one tap and a flat row mapping.
 #include "conv_common.h"
-#include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -36,15 +35,6 @@ struct Conv16Args {
     int slab16;                                // split-K partial slabs in fp16 (see the epilogue) instead of fp32
 };
 
-#ifndef DDNM_P16_EARLY_RES
-#define DDNM_P16_EARLY_RES 1        // build-time probe switch: 0 = load the residual tile after the LDS staging
-#endif
-#ifndef DDNM_P16_LATE_DMA
-#define DDNM_P16_LATE_DMA 1         // build-time probe switch: 0 = request the next step's tiles right after the barrier
-#endif
-#ifndef DDNM_P16_ILV
-#define DDNM_P16_ILV 1              // build-time probe switch (tools/conv16_probe.py): 0 = read burst before the MFMAs
-#endif
 constexpr int C16_KC = 64;          // channels per chunk (= 128 bytes per LDS row)
 constexpr int C16_BN = 256;
 constexpr int C16_ROWB = 128;       // LDS row pitch in bytes
@@ -171,9 +161,6 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     auto issue_w = [&](__amdgpu_buffer_rsrc_t rsrc, unsigned rowlen, unsigned delta, int wb) {
         char* dst = Wb + wb * G::WBYTES + wave * 1024;
         const unsigned vo = (wrow0 * rowlen + lp8) * 2u;
-#ifdef DDNM_P16_NO_WLOAD
-        if (rowlen != 12345u) return;
-#endif
         if (WNW == 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bload16(rsrc, vo, (delta + 64u * j * rowlen) * 2u, dst + j * 8192);
@@ -262,13 +249,8 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         for (int i = 0; i < MT; ++i) b[0][i] = *reinterpret_cast<const half8*>(lds + pb[i]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-#ifdef DDNM_P16_NO_FRAG
-            const int cur = 0, nxt = 0;
-            if (false) {
-#else
             const int cur = ks & 1, nxt = cur ^ 1;
             if (ks + 1 < 4) {
-#endif
 #pragma unroll
                 for (int j = 0; j < NT; ++j) a[nxt][j] = *reinterpret_cast<const half8*>(lds + (wo[j] ^ ((ks + 1) << 5)));
 #pragma unroll
@@ -276,7 +258,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             }
             // 9-tap kernels: one LDS read of the next k-step behind each of the first MFMAs (-4 % vs a read burst up
             // front); the 1-tap GEMM form measured better with the burst (its steps are dominated by the tile loads)
-            constexpr bool ILV = DDNM_P16_ILV && TAPS == 9 && MT * NT >= MT + NT;
+            constexpr bool ILV = TAPS == 9 && MT * NT >= MT + NT;
             if (!ILV) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -328,11 +310,7 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     };
-#ifdef DDNM_P16_NO_MAIN
-    if (false) {
-#else
     if (n_main > 0) {
-#endif
         issue_main_halo(c_begin, 0);
         if (fuse_gn) issue_gn(c_begin);
         issue_w(r_w, wrow, (unsigned)(c_begin * C16_KC), 0);
@@ -359,20 +337,14 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         }
     }
 #pragma unroll 1
-#ifdef DDNM_P16_NO_MAIN
-    for (int c = c_end; c < c_end; ++c) {
-#else
     for (int c = c_begin; c < c_end; ++c) {
-#endif
         const bool more = c + 1 < c_end;
         int toff = 0, kx = 0;
         // (rolled on purpose: unrolled, the compiler hoists 9 x 16 loop-invariant fragment addresses and spills)
 #pragma unroll 1
         for (int tap = 0; tap < TAPS; ++tap) {
             wait_tiles();
-#ifndef DDNM_P16_NO_SYNC
             __builtin_amdgcn_s_barrier();           // this step's tiles have landed (every wave's); the oldest buffers are free
-#endif
             auto issue_next = [&]() {
                 pend = false;
                 if (TAPS == 9) {
@@ -392,14 +364,9 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
                 // 1-tap form: the step after this one finds min(LA - 1, steps left after it) younger groups in flight
                 if (TAPS == 1) { const int left = c_end - 2 - c; ahead = left < LA - 1 ? (left < 0 ? 0 : left) : LA - 1; }
             };
-#if DDNM_P16_LATE_DMA
             // the next tiles are requested behind the first 8 MFMAs: the LDS-DMA issue (M0 set-up, 5-10 buffer
             // loads) no longer sits between the barrier and the first fragment reads
             mfma_step(toff, hb, wb, issue_next);
-#else
-            issue_next();
-            mfma_step(toff, hb, wb, [] {});
-#endif
             // the next chunk's halo and parameters landed before this step's barrier (tap >= 1): one 8-row piece is
             // activated per tap
             if (fuse_gn && more && tap >= 1 && tap <= G::HG_PER_WAVE) {
@@ -472,23 +439,10 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
         if (!wave_on) pix = -1;
         opix[it] = pix;
         rv[it] = uint4{0u, 0u, 0u, 0u};
-        if (DDNM_P16_EARLY_RES && p.ksplit == 1 && WNW == 4 && res && pix >= 0) rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
+        if (p.ksplit == 1 && WNW == 4 && res && pix >= 0) rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
     }
     __syncthreads();                   // all fragment reads done: LDS becomes the epilogue's staging area
 
-#ifdef DDNM_P16_NO_EPI
-    {   // probe: keep the accumulators live, write almost nothing
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-        if (t == 12345.678f) reinterpret_cast<_Float16*>(d.out)[tid] = (_Float16)t;
-        return;
-    }
-#endif
     // ================================================================ epilogue
     // D layout (32x32 MFMA, A = weights): lane -> pixel = lane & 31 of M tile i, channels
     // wn*64 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3).
@@ -555,19 +509,6 @@ __global__ __launch_bounds__(512) void conv16_kernel(const Conv16Args p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-#if !DDNM_P16_EARLY_RES
-#pragma unroll
-    for (int it = 0; it < ITS; ++it)
-        if (res && opix[it] >= 0) {
-            const int m = wm * MT * 32 + it * 8 + lrow;
-            int rpix = opix[it];
-            if (TAPS == 9 && d.res_ups) {
-                const int oy = ty0 + (m >> TWl), ox = tx0 + (m & (TW - 1));
-                rpix = (img * (d.H >> 1) + (oy >> 1)) * (d.W >> 1) + (ox >> 1);
-            }
-            rv[it] = *reinterpret_cast<const uint4*>(res + (size_t)rpix * d.Cout + chn);
-        }
-#endif
     float cs[8], cq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
@@ -1173,30 +1114,12 @@ static __global__ __launch_bounds__(C16_FIN_THREADS) void conv16_splitk_reduce_f
     }
 }
 
-// fp16 split-K slabs (default); DDNM_P16_SLAB32=1 keeps the fp32 slabs of rounds 2-3 (A/B switch).  The workspace the
-// host provides is sized for fp32 slabs either way (ddnm_conv16_workspace_floats).
-static bool slab16_enabled() {
-    static const bool on = [] { const char* e = getenv("DDNM_P16_SLAB32"); return !(e && e[0] == '1'); }();
-    return on;
-}
-
 // ---------------------------------------------------------------------------------------------
-static bool n128_wide() {
-    static const bool on = [] { const char* e = getenv("DDNM_P16_N128_WIDE"); return e && e[0] == '1'; }();
-    return on;
-}
-
 struct Plan16 {
     int taps, MT, TW, TW_log2, tiles_x, tiles_per_img, m_tiles, n_tiles, ksplit, stats_tiles, small;
     int fin_cs;          // > 0: the split-K reduction finalizes the consumer's GroupNorm, slabs of fin_cs channels
     int n128;            // 1: conv16_n128_kernel (256 pixels x 128 channels, 4 waves, two workgroups per CU)
 };
-
-// 256 x 128 tiles for Cout = 128 (default); DDNM_P16_N128=0 keeps such launches on the 256-channel tile (A/B switch)
-static bool n128_enabled() {
-    static const bool on = [] { const char* e = getenv("DDNM_P16_N128"); return !(e && e[0] == '0'); }();
-    return on;
-}
 
 // channel slab of the finalizing reduction (0: this launch cannot / need not finalize): whole groups, 16 .. 64 channels,
 // images of at most 1024 pixels (one workgroup walks all of them)
@@ -1263,13 +1186,10 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
     // the 256-pixel tile unless it cannot give most of the 256 CUs a workgroup and the 128-pixel tile can
     int best_mt = tiles_of[4] > 0 ? 4 : (tiles_of[2] > 0 ? 2 : 0);
     if (tiles_of[4] < 200 && tiles_of[2] > tiles_of[4]) best_mt = 2;
-#ifndef DDNM_P16_MT1
-#define DDNM_P16_MT1 1              // build-time probe switch: 0 = no 64-pixel tiles
-#endif
     // 1x1 convolutions / im2col'ed GEMMs whose 128-pixel tiling leaves half of the CUs without a workgroup (qkv and
     // proj_out of the 8^2 .. 32^2 attention blocks: 8 .. 96 tiles, each a chain of <= 16 steps): 64-pixel tiles double the
     // workgroups of the one round and halve its length; split-K launches get half as many fp32 slabs
-    if (DDNM_P16_MT1 && pl->taps == 1 && best_mt == 2 && tiles_of[2] <= 128 && tiles_of[1] > tiles_of[2]) best_mt = 1;
+    if (pl->taps == 1 && best_mt == 2 && tiles_of[2] <= 128 && tiles_of[1] > tiles_of[2]) best_mt = 1;
     if (best_mt == 0) return false;
     pl->MT = best_mt;
     const int bm = 64 * best_mt;
@@ -1296,16 +1216,13 @@ static bool plan16(const ddnm_conv16_desc* d, Plan16* pl) {
         // a 1x1 convolution with K <= 1024 is at most 16 steps: slicing it costs more (fp32 slabs + the reduction
         // launch) than the idle CUs do (measured 1024 -> 1024 @16^2: 25.7 -> 17.7 us, 512 -> 512 @32^2: 32.8 -> 12.5 us)
         if (pl->taps == 1 && nchunks <= 16 && hw % bm == 0) ks = 1;
-#ifdef DDNM_P16_KSCAP               // build-time probe: cap on the split-K factor
-        if (ks > DDNM_P16_KSCAP) ks = DDNM_P16_KSCAP;
-#endif
         if (ks < 1) ks = 1;
     }
     pl->ksplit = ks;
     // Cout = 128 on 256-pixel tiles, enough of them for two workgroups per CU to matter, no fused shortcut
-    // (DDNM_P16_N128_WIDE=1, experiment: every Cout that is a multiple of 128, as Cout / 128 channel tiles)
-    pl->n128 = (pl->taps == 9 && best_mt == 4 && ks == 1 && !d->skip0 && pl->m_tiles >= 128 && n128_enabled() &&
-                (d->Cout == 128 || (n128_wide() && d->Cout % 128 == 0))) ? 1 : 0;
+    // (for Cout >= 256 the same kernel with Cout / 128 channel tiles measured SLOWER than the 256-channel tile: every pixel
+    // tile's halo is fetched and activated once per channel tile; tools/experiments/HISTORY.md)
+    pl->n128 = (pl->taps == 9 && best_mt == 4 && ks == 1 && !d->skip0 && pl->m_tiles >= 128 && d->Cout == 128) ? 1 : 0;
     pl->fin_cs = fin_slab16(d, ks);
     if (pl->fin_cs > 0) pl->stats_tiles = 1;
     else if (ks > 1) pl->stats_tiles = splitk_tiles16(d);
@@ -1377,15 +1294,12 @@ extern "C" int ddnm_conv16(const ddnm_conv16_desc* d, void* stream) {
     p.M = d->B * d->H * d->W;
     p.Hs = d->ups ? d->H / 2 : d->H;
     p.Ws = d->ups ? d->W / 2 : d->W;
-#ifndef DDNM_P16_WMAJOR_MAXM
-#define DDNM_P16_WMAJOR_MAXM 8
-#endif
     // weight bytes > activation bytes, and few enough pixel tiles per weight stream that one XCD's CUs do not all pull
     // the same weight lines at the same moment (32 sharers measured SLOWER than replicating the weights over XCDs)
-    p.wmajor = ((long)d->Cout * pl.taps > (long)p.M && pl.m_tiles <= DDNM_P16_WMAJOR_MAXM) ? 1 : 0;
+    p.wmajor = ((long)d->Cout * pl.taps > (long)p.M && pl.m_tiles <= 8) ? 1 : 0;
     // fp16 slabs for up to 8 slices only: every partial sum is rounded to fp16 once, so the added error grows like
     // sqrt(ksplit) * 2^-12 of a partial's magnitude; deeper splits keep fp32 slabs
-    p.slab16 = (slab16_enabled() && pl.ksplit <= 8) ? 1 : 0;
+    p.slab16 = pl.ksplit <= 8 ? 1 : 0;        // fp16 split-K slabs up to 8 slices, fp32 beyond (the workspace is sized for fp32 either way)
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(pl.m_tiles * pl.n_tiles * pl.ksplit);
     if (pl.small) {

@@ -175,13 +175,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, const TileMap& 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[i][j][r] * acc_scale + add + rv[r];
-#ifdef DDNM_PROBE_NO_STORE            // timing probe: everything but the global stores (wrong results)
-                if (v == 12345.678f)
-#endif
-                {
                 if (partial) ws[o[r]] = v;
                 else out[o[r]] = v;
-                }
                 cs[j] += v;
                 cq[j] = __builtin_fmaf(v, v, cq[j]);      // explicit: every kernel that shares this epilogue (and conv_s16_persist.hip) rounds alike
             }

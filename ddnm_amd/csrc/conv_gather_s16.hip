@@ -265,10 +265,7 @@ extern "C" int ddnm_conv_gather_s16_f32(const ddnm_conv_desc* d, void* stream) {
     if (d->C1 > 0 && !d->src1) return DDNM_E_BADARG;
     if (d->gn_scale && !d->gn_shift) return DDNM_E_BADARG;
     if (!(d->acc_scale > 0.f)) return DDNM_E_BADARG;
-    {   // a raw operand needs the operand bound (fp16 range); DDNM_S16_UNGUARDED=1 lifts that for probes
-        static const bool unguarded = [] { const char* e = getenv("DDNM_S16_UNGUARDED"); return e && e[0] == '1'; }();
-        if (!d->gn_scale && !d->amax_in && !unguarded) return DDNM_E_BADARG;
-    }
+    if (!d->gn_scale && !d->amax_in) return DDNM_E_BADARG;      // a raw operand needs the operand bound (fp16 range)
     if (d->ups && ((d->Hin | d->Win) & 1)) return DDNM_E_SHAPE;
     if (d->res_ups && ((d->Ho | d->Wo) & 1)) return DDNM_E_SHAPE;
     PlanGS pl;

@@ -55,9 +55,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
     // written through registers, behind the GroupNorm + swish prologue).
     constexpr int BSF = BN * KC;                          // floats per weight buffer
     __shared__ __attribute__((aligned(1024))) float lds_all[NBUF * BSF + MAXH * LDT
-#ifdef DDNM_PROBE_LDS_PAD
-                                                            + DDNM_PROBE_LDS_PAD
-#endif
     ];
     float* const Bs = lds_all;
     float* const Hs = lds_all + NBUF * BSF;
@@ -87,14 +84,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 
     // K range of this workgroup (channel chunks)
     const int nchunks = p.Cin / KC;
-#ifdef DDNM_PROBE_DEPHASE             // timing probe (wrong results): a subset of the FIRST round's workgroups skips the
-                                      // first half of K, so that they run half a tile out of phase for the rest of the launch
-    const bool dephase_short = DDNM_PROBE_DEPHASE == 1 ? (blockIdx.x >= 256 && blockIdx.x < 512)
-                                                       : (blockIdx.x < 512 && ((blockIdx.x >> 3) & 1));
-    const int c_begin = dephase_short ? nchunks / 2 : 0, c_end = nchunks;
-#else
     const int c_begin = (int)((long)nchunks * slice / p.ksplit), c_end = (int)((long)nchunks * (slice + 1) / p.ksplit);
-#endif
 
     f32x4 h_st[HR], b_st[BR];
     f32x4 gsc = {1.f, 1.f, 1.f, 1.f}, gsh = {0.f, 0.f, 0.f, 0.f};
@@ -140,9 +130,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
             const int row = prow + 32 * i;
             if (row < MAXH) {
                 f32x4 v = h_st[i];
-#ifndef DDNM_PROBE_NO_GN
                 if (apply_gn && has_gn && hoff[i] >= 0) v = gn_act(v, gsc, gsh, d.gn_silu);
-#endif
                 *reinterpret_cast<f32x4*>(&Hs[row * LDT + c4 * 4]) = v;
             }
         }
@@ -179,20 +167,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int tap_off = (ky * HWd + kx) * LDT;
         const char* bbase = reinterpret_cast<const char*>(Bs + buf * BSF);
-#ifdef DDNM_PROBE_NO_FRAG          // timing probe (wrong results): one set of fragment reads per tap instead of four
-        f32x4 a[MT], b[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Hs + a_off[i] + tap_off);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(bbase + b_frag + j * 32 * KC * 4);
-#pragma unroll
-        for (int kk = 0; kk < KC / 8; ++kk) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[i], b[j], acc[i][j]);
-        }
-#else
         // explicit two-deep fragment pipeline: the reads of k-step kk+1 are in flight under the 16 MFMAs of kk
         f32x4 a[2][MT], b[2][NT];
 #pragma unroll
@@ -215,16 +189,12 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
                 for (int j = 0; j < NT; ++j) acc[i][j] = mfma_k8(a[cur][i], b[cur][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
     };
 
     // ---- weight tile double-buffered, by LDS-DMA: per tap  [barrier: B(s) landed, buffer of B(s-1) free |
     //      request B(s+1) into it | MFMA(s)];  the halo is re-staged between two barriers at every chunk boundary.
     // The request flies under the 64 MFMAs per wave of a tap and is drained by the `vmcnt(0)` of the next tap's
     // barrier; no staging registers, no ds_write pass, no wait on a register destination inside the loop.
-#ifdef DDNM_PROBE_SETPRIO_HALF      // probe: static priority for the younger half of the waves (MI355X_MICROARCH.md)
-    if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     if (c_begin < c_end) {
         prefetch_halo(c_begin);
         issue_w(c_begin, 0, 0);
@@ -234,25 +204,13 @@ __global__ __launch_bounds__(256) void conv3x3_halo_f32_kernel(const ConvArgs p)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const bool last_tap = tap == 8, more = chunk + 1 < c_end;
-#ifndef DDNM_PROBE_NO_SYNC           // timing probe (wrong results): no barrier per tap
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of B(s) (and of the halo prefetch)
                 __syncthreads();                                        // everybody's; B(s-1) and (tap 0) the halo are free
-#endif
-#ifndef DDNM_PROBE_NO_WL             // timing probe (wrong results): no weight requests inside the tap loop
                 if (!last_tap) issue_w(chunk, tap + 1, cur ^ 1);
                 else if (more) issue_w(chunk + 1, 0, cur ^ 1);
-#endif
                 if (tap == 7 && more) prefetch_halo(chunk + 1);         // registers; staged after tap 8
-#ifndef DDNM_PROBE_NO_PIN
                 __builtin_amdgcn_sched_barrier(0);      // requests in FRONT of the MFMAs (the scheduler sinks them otherwise)
-#endif
-#ifdef DDNM_PROBE_SETPRIO_MFMA      // probe: the MFMA burst of a tap at raised wave priority
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 mfma_tap(tap, cur);
-#ifdef DDNM_PROBE_SETPRIO_MFMA
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 if (last_tap && more) {                     // chunk boundary: every wave must be done with Hs
                     __syncthreads();
                     stage_halo();

@@ -41,22 +41,23 @@ enum { K_MID = 0, K_LAST = 1, K_FIRST = 2 };
 
 // Requests a wave issues at the END of a tap's issue block (behind the weight-tile DMA and the halo loads) on top of the
 // one-tile kernel's stream: FIRST chunk of a tile = the previous tile's deferred stores (+ 1 statistics store at tap 0),
-// LAST chunk = bias / per-sample addend (4 at tap 0) and, with a residual, its 64 loads.  Nothing at taps 7 / 8, so a
-// chunk's table does not depend on its neighbours.
+// LAST chunk = bias / per-sample addend (4 at tap 0), the next tile's operand bound (1 at tap 0, ASCALE instances) and, with
+// a residual, its 64 loads.  Nothing at taps 7 / 8, so a chunk's table does not depend on its neighbours.
 constexpr int p_spread(int tap) { return tap == 0 ? 10 : (tap <= 6 ? 9 : 0); }
 constexpr int p_first_of(int tap) { return tap == 0 ? 0 : (tap <= 7 ? 10 + 9 * (tap - 1) : P_NOUT); }
 static_assert(p_first_of(7) == P_NOUT, "64 values over taps 0..6");
-constexpr int p_extra(int kind, int tap, bool has_res) {
-    return kind == K_FIRST ? p_spread(tap) + (tap == 0 ? 1 : 0) : (kind == K_LAST ? (tap == 0 ? 4 : 0) + (has_res ? p_spread(tap) : 0) : 0);
+constexpr int p_extra(int kind, int tap, bool has_res, bool ascale) {
+    return kind == K_FIRST ? p_spread(tap) + (tap == 0 ? 1 : 0)
+                           : (kind == K_LAST ? (tap == 0 ? 4 + (ascale ? 1 : 0) : 0) + (has_res ? p_spread(tap) : 0) : 0);
 }
 constexpr int p_base(int tap) {
     return (tap == 1 || tap == 2) ? P_BR + P_HSPLIT + 2 : ((tap == 4 || tap == 5) ? P_BR + P_HR - P_HSPLIT : P_BR);
 }
 // vmcnt immediate of the wait in front of tap `tap`: everything issued behind W(tap) (requested first thing at tap - 2)
-constexpr int p_wait(int kind, int tap, bool has_res) {
-    return p_base(tap) + (tap >= 1 ? p_extra(kind, tap - 1, has_res) : 0) + (tap >= 2 ? p_extra(kind, tap - 2, has_res) : 0);
+constexpr int p_wait(int kind, int tap, bool has_res, bool ascale) {
+    return p_base(tap) + (tap >= 1 ? p_extra(kind, tap - 1, has_res, ascale) : 0) + (tap >= 2 ? p_extra(kind, tap - 2, has_res, ascale) : 0);
 }
-static_assert(p_wait(K_FIRST, 2, true) < 64, "vmcnt is a 6-bit field");
+static_assert(p_wait(K_FIRST, 2, true, true) < 64 && p_wait(K_LAST, 2, true, true) < 64, "vmcnt is a 6-bit field");
 
 template <int V>
 using ic = std::integral_constant<int, V>;
@@ -134,6 +135,30 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
     const __amdgpu_buffer_rsrc_t r_s1 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(reinterpret_cast<const void*>(d.C1 > 0 ? d.src1 : d.src0)), 0,
         (unsigned)d.B * p.Hs * p.Ws * (d.C1 > 0 ? d.C1 : d.C0) * 4, 0x00020000);
+    // Operand-range guard (ASCALE: raw operands; conv_common.h::s16_operand_scale restated for a request stream that must
+    // stay countable): the DDNM_AMAX_N bound words of an image are ONE buffer load per wave (lane l < 32 fetches word l; the
+    // one-tile kernel's scalar loads would become vector loads here -- the kernel stores, so nothing is provably
+    // unclobbered -- in a number the compiler chooses), the maximum is a wave reduction on the bit patterns.
+    const __amdgpu_buffer_rsrc_t r_amax = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(d.amax_in)), 0, d.amax_in ? (unsigned)d.B * DDNM_AMAX_N * 4u : 0u, 0x00020000);
+    auto amax_request = [&](int img, bool live) {
+        return __builtin_amdgcn_raw_buffer_load_b32(r_amax, (lane < DDNM_AMAX_N && live) ? (unsigned)lane * 4u : HOOB, (unsigned)img * DDNM_AMAX_N * 4u, 0);
+    };
+    auto amax_scales = [&](unsigned m, bool down_only, float& scale, float& inv_scale) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)m, o);
+            m = t > m ? t : m;
+        }
+        m = __builtin_amdgcn_readfirstlane(m);
+        int e = (int)((m >> 23) & 0xffu);
+        e = e < 47 ? 47 : (e > 207 ? 207 : e);
+        int k = 14 - (e - 127);
+        if (down_only && k > 0) k = 0;
+        scale = __uint_as_float((unsigned)(127 + k) << 23);
+        inv_scale = __uint_as_float((unsigned)(127 - k) << 23);
+    };
+    unsigned amax_bits = 0;                           // the next tile's bound words, requested at the LAST chunk's tap 0
     int gn_img = 0;                                   // image whose GroupNorm vectors the next prefetch fetches
     float ascale_stage = 1.f;                         // operand scale of the halo being staged (ASCALE)
     auto prefetch_halo_part = [&](int chunk, int i0, int i1, bool live = true) {
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
     cur_stats = (unsigned)((t_mtile * Cout + t_ntile * BN) * 8);
     if constexpr (ASCALE) {
         float inv;
-        s16_operand_scale(d.amax_in, t_img, has_gn, ascale_stage, inv);
+        amax_scales(amax_request(t_img, true), has_gn, ascale_stage, inv);       // nothing else is in flight yet
         epi_cur = d.acc_scale * inv;
     }
     prefetch_halo_part(0, 0, HR);
@@ -309,7 +334,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
     stage_halo_part(0, 0, HR);
     if (wave >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);       // one wave of each SIMD pair at raised priority (conv_igemm_f16.hip)
 
-    int hb = 0;
+    int hb = 0, n_img_next = 0;
     bool have_next = false;
     float epi_next = epi_cur;
     unsigned next_base = 0, next_stats = 0, next_wsoff = 0;
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
     auto tap_body = [&](auto KIND, auto TAP, int chunk) {
         constexpr int kind = decltype(KIND)::value, tap = decltype(TAP)::value;
         constexpr int cur = tap % NWB;
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(p_wait(kind, tap, HAS_RES)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(p_wait(kind, tap, HAS_RES, ASCALE)) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // weight tile of step + 2 into the buffer W(step - 1) just left; the LAST chunk's taps 7 / 8 request the next tile's
@@ -336,6 +361,13 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
         const bool live = kind == K_LAST ? have_next : true;
         if constexpr (tap == 0) prefetch_halo_part(nchunk, 0, HSPLIT, live);
         if constexpr (tap == 3) {
+            if constexpr (kind == K_LAST && ASCALE) {         // the next tile's operand scale, from the words requested at tap 0
+                if (have_next) {
+                    float inv;
+                    amax_scales(amax_bits, has_gn, ascale_stage, inv);
+                    epi_next = d.acc_scale * inv;
+                }
+            }
             if (live) stage_halo_part(hb ^ 1, 0, HSPLIT);
             prefetch_halo_part(nchunk, HSPLIT, HR, live);
         }
@@ -353,6 +385,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
         }
         if constexpr (kind == K_LAST) {
             if constexpr (tap == 0) {
+                if constexpr (ASCALE) amax_bits = amax_request(n_img_next, have_next);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     addv[j][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_bias, c_lane + j * 128, (unsigned)(t_ntile * BN * 4), 0));
@@ -401,11 +434,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
             next_wsoff = (unsigned)t_ntile * BN * w_rowlen;
             next_base = tile_base();
             next_stats = (unsigned)((t_mtile * Cout + t_ntile * BN) * 8);
-            if constexpr (ASCALE) {
-                float inv;
-                s16_operand_scale(d.amax_in, t_img, has_gn, ascale_stage, inv);
-                epi_next = d.acc_scale * inv;
-            }
+            n_img_next = t_img;
         }
         {   // bias / addend of the CURRENT tile: tap_body reads t_img / t_ntile
             const int n_img = t_img, n_ntile = t_ntile;

@@ -247,8 +247,9 @@ extern "C" int ddnm_embedding_add_f32(float* emb, const float* table, const int6
 // ABI version: bumped whenever a descriptor struct or a prototype of include/ddnm_hip.h changes
 // (2: ddnm_conv16_desc and the fp16-activation entry points, ddnm_build_digest, ddnm_sizeof; 3: ddnm_conv16_desc::fin_*;
 // 4: ddnm_conv_desc::acc_scale and the split-fp16 entry points ddnm_conv3x3_s16_*; 5: ddnm_conv_desc::amax_in;
-// 6: the fp16-activation classifier entry points ddnm_gn_bwd_h16, ddnm_pool_tokens*_h16, ddnm_attn16_d64_lse / _bwd).
-extern "C" int ddnm_version(void) { return 6; }
+// 6: the fp16-activation classifier entry points ddnm_gn_bwd_h16, ddnm_pool_tokens*_h16, ddnm_attn16_d64_lse / _bwd;
+// 7: ddnm_conv_desc::flags (was reserved0), ddnm_step_srconv_* removed, no environment variable is read by the library).
+extern "C" int ddnm_version(void) { return 7; }
 
 // sha256 of the sources + flags this binary was compiled from (ddnm_amd/build.py passes it with -D); the loader
 // (ddnm_amd/_lib.py) compares it with the digest of the sources next to it and refuses a stale binary.

@@ -32,7 +32,7 @@ def init(backend=None, force=False):
     global _COLLECTIVES_AT_WORLD_1
     rank, local_rank, world = env_world()
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if world == 1 and (force or launched) and os.environ.get("DDNM_DIST_WORLD1", "1") != "0":
+    if world == 1 and (force or launched):
         _COLLECTIVES_AT_WORLD_1 = True
     if (world > 1 or _COLLECTIVES_AT_WORLD_1) and not dist.is_initialized():
         if backend is None:

@@ -130,7 +130,7 @@ class _GuidanceAhead:
     classifier conditions per sample, so this IS the reference's computation for each of the steps): the low-resolution
     half of the classifier is a chain of launches whose time does not depend on the batch, and one chain now serves G
     steps.  Same inputs, same arithmetic; the launch plans of a batch of G n differ from those of n in summation order
-    only (fp32: ~1e-7).  DDNM_CLS_PAIR=0 evaluates step by step (bit-identical to the serial order), DDNM_CLS_OVERLAP=0
+    only (fp32: ~1e-7).  DDNM_CLS_GROUP=1 evaluates step by step (bit-identical to the serial order), DDNM_CLS_OVERLAP=0
     restores the serial order on the main stream."""
 
     def __init__(self, cls_fn, x, n, t_values, t_of=None, cls=None):
@@ -141,12 +141,11 @@ class _GuidanceAhead:
         self.t_values, self.pos = t_values, 0
         self.serial = os.environ.get("DDNM_CLS_OVERLAP") == "0"
         # steps per guidance pass: DDNM_CLS_GROUP (default 4: c5 at B = 8 on one MI355X 2.92 / 3.00 / 3.03 / 3.04 images/s
-        # for 1 / 2 / 3 / 4, same box; 1 or 0 = step by step, bit-identical to the serial order; DDNM_CLS_PAIR=0 is the
-        # older spelling of that).  ONLY the engine's own cond_fn is grouped (`make_cond_fn` marks it): a foreign callable
+        # for 1 / 2 / 3 / 4, same box; 1 or 0 = step by step, bit-identical to the serial order).  ONLY the engine's own cond_fn is grouped (`make_cond_fn` marks it): a foreign callable
         # -- e.g. the reference's torch-autograd closure -- sees exactly the reference's calls (n images, one timestep),
         # because grouping multiplies its activation memory by G and assumes a strictly per-sample classifier.
         grp = int(os.environ.get("DDNM_CLS_GROUP", "4"))
-        if os.environ.get("DDNM_CLS_PAIR", "1") == "0" or grp < 1 or getattr(cls_fn, "ddnm_engine", None) is None:
+        if grp < 1 or getattr(cls_fn, "ddnm_engine", None) is None:
             grp = 1
         # ... capped so that the replicated batch stays within what one convolution launch can address (2 GiB per
         # tensor): 32 images for the fp32-tensor engines (128 channels at 256 x 256), 64 for the fp16-activation one
@@ -173,7 +172,7 @@ class _GuidanceAhead:
             # are keyed by the stream handle, a fresh stream per call would grow them by one set per batch
             # (measured on c5, one MI355X: high priority 2.85 -> 2.99 images/s for step-by-step evaluation; with four steps
             # per pass the chain has four UNet steps to hide behind and normal priority is ahead, 3.034 vs 3.011)
-            self.side = _side_stream(x.device, int(os.environ.get("DDNM_CLS_PRIO", "-1" if self.group == 1 else "0")))
+            self.side = _side_stream(x.device, -1 if self.group == 1 else 0)
             self.side.wait_stream(self.main)             # x (and the operator's set-up) are complete
             self._launch()
 
@@ -229,11 +228,18 @@ _PHILOX_CALLS = [0]
 
 
 def _philox_for_call(like):
-    """Key of an un-pinned run: the device generator's seed (torch.manual_seed / torch.cuda.manual_seed_all set it, like
-    the reference's main.py:139-143) and a per-call counter, so that consecutive restorations draw different noise."""
-    seed = torch.cuda.initial_seed() if like.is_cuda else torch.initial_seed()
+    """Key of an un-pinned run (`noise=None`): a 64-bit hash of the device generator's FULL seed (torch.manual_seed /
+    torch.cuda.manual_seed_all set it, like the reference's main.py:139-143), a per-call counter -- consecutive restorations
+    draw different noise -- and the rank of the calling process, so that the ranks of a sharded programmatic run do not draw
+    identical noise for different images.  Callers that want rank-count-independent results pin the generator:
+    `noise=ops.PhiloxNoise(seed, image_base=<global index of image 0>)`, as the runner does; DDNM_NOISE=torch = ATen draws."""
+    seed = int(torch.cuda.initial_seed() if like.is_cuda else torch.initial_seed())
     _PHILOX_CALLS[0] += 1
-    return ops.PhiloxNoise((int(seed) & 0xFFFFFFFF) | ((_PHILOX_CALLS[0] & 0xFFFFFFFF) << 32))
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    z = (seed * 0x9E3779B97F4A7C15 + _PHILOX_CALLS[0] * 0xBF58476D1CE4E5B9 + (rank + 1) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return ops.PhiloxNoise(z ^ (z >> 31))
 
 
 def _noise_source(noise, like):

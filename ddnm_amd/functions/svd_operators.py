@@ -786,9 +786,6 @@ class SRConv(A_functions):
         self.singulars_small = S.to(device)
         self.Ae = ((U * S[None, :]) @ V[:, :small].T).contiguous().to(device)       # [small, img_dim]
         self.Pe = ((V[:, :small] * Sp[None, :]) @ U.T).contiguous().to(device)      # [img_dim, small]
-        # transposed copies for the two-launch step kernel (csrc/sr_step.hip); built once here like Ae / Pe themselves
-        self.AeT, self.PeT = self.Ae.t().contiguous(), self.Pe.t().contiguous()
-        self._step_ws = None
         self._svd_host = (U.contiguous(), V.contiguous())     # factors of the spectral surface (V / Vt / U / Ut), built lazily
 
     # ---- matrix-free SVD surface (svd_operators.py:886-931); the sampling path uses the Ae / Pe forms above
@@ -876,20 +873,6 @@ class SRConv(A_functions):
 
     def ddnm_step(self, xt, et, noise, y, s, x0_out, xt_next):
         B = xt.shape[0]
-        L = _lib.lib()
-        need = L.ddnm_step_srconv_workspace_floats(B, self.channels, self.img_dim, self.small_dim)
-        if need > 0 and os.environ.get("DDNM_SR_STEP_FUSED") == "1":
-            # 256 x 256, 4x: the whole step in two launches (x0 + Ae X Ae^T partials | R, Pe R Pe^T, DDIM update).  Opt-in:
-            # measured against the six-launch route below (x0 kernel, four MFMA GEMMs, combine) on the headline workload it
-            # is 0.3 % SLOWER (5.969 / 5.951 vs 5.986 / 5.974 images/s, alternating runs on one box): 96 workgroups of fp32
-            # vector FMAs take as long as the launches they save (tools/experiments/HISTORY.md)
-            if self._step_ws is None or self._step_ws.numel() < need:
-                self._step_ws = torch.empty(need, dtype=torch.float32, device=xt.device)
-            ep, es = ops._et_args(et)
-            check(L.ddnm_step_srconv_f32(_p(xt), ep, es, _p(noise), _p(y), _p(self.AeT), _p(self.PeT), _p(self._step_ws),
-                                         _p(x0_out), _p(xt_next), B, self.channels, self.img_dim, self.small_dim,
-                                         ctypes.byref(s), ops._stream()), "ddnm_step_srconv_f32")
-            return
         ops.step_x0(xt, et, s, out=x0_out)
         resid = self._A(x0_out, y_sub=y.reshape(B, -1))          # A x0 - y fused in the GEMM epilogue
         proj = self.A_pinv(resid).reshape(xt.shape)

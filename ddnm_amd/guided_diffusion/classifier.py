@@ -63,6 +63,9 @@ def create_classifier(image_size, classifier_use_fp16, classifier_width, classif
                             resblock_updown=classifier_resblock_updown, pool=classifier_pool)
 
 
+# module attribute (tests): False evaluates the timestep-independent prefix of a grouped pass for every replica
+SHARE_PREFIX = True
+
 class EncoderUNetModel:
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  channel_mult=(1, 2, 4, 8), use_fp16=False, num_head_channels=-1, use_scale_shift_norm=False,
@@ -112,7 +115,7 @@ class EncoderUNetModel:
         """Images one pass may hold: the largest activation (model_channels at image_size^2) must stay below the 2 GiB a
         convolution launch can address -- 4 bytes per element for the fp32-tensor engines, 2 for the fp16-activation one."""
         per_image = self.image_size * self.image_size * self.model_channels * (2 if (self.use_fp16 and self.h16) else 4)
-        return ops.max_launch_batch(per_image, margin=2)    # half of the addressable limit: 32 / 64 at 256 x 256 x 128
+        return ops.max_launch_batch(per_image)    # half of the addressable limit: 32 / 64 at 256 x 256 x 128
 
     # ------------------------------------------------------------------ nn.Module-like surface
     def to(self, device):
@@ -411,7 +414,7 @@ class EncoderUNetModel:
         B = x.shape[0]
         first = self.input_blocks[1][0] if len(self.input_blocks) > 1 else None
         share = (replicas > 1 and B % replicas == 0 and first is not None and first[0] == "res" and first[3] == ""
-                 and first[1] == first[2] and os.environ.get("DDNM_CLS_SHARE_PREFIX") != "0")
+                 and first[1] == first[2] and SHARE_PREFIX)
         shared = None
         if share:
             G, nu = replicas, B // replicas

@@ -187,6 +187,14 @@ def simple_checkpoint_path(config, exp):
     raise ValueError(f"no checkpoint family for dataset {ds!r} with model.type=simple")   # CIFAR10 is not a DDNM config
 
 
+def _mix64(seed, k):
+    """64-bit key of (run seed, batch index): splitmix64 finaliser, so that neighbouring seeds / batches share no key bits."""
+    z = (int(seed) * 0x9E3779B97F4A7C15 + int(k) * 0xBF58476D1CE4E5B9 + 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
 class BatchNoise:
     """Noise of one loader batch, independent of how the batch is sharded: x_T and the tensor of loop iteration k are
     drawn for ALL `n` images from a generator seeded by (seed, batch index) -- in a fixed order -- and sliced to
@@ -367,18 +375,38 @@ class Diffusion(object):
         idx_so_far = args.subset_start
         psnr_sum, n_done = 0.0, 0
         C, S = config.data.channels, config.data.image_size
-        if rank == 0:
-            os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)
+        os.makedirs(os.path.join(args.image_folder, "Apy"), exist_ok=True)      # (rank 0 made the image folder before the first barrier)
+        # Sharding (one process per GPU): a loader batch of at least `world` images is split by image index and gathered once;
+        # SMALLER batches -- every shipped config has sampling.batch_size 1 -- are dealt whole, round-robin, each rank writing
+        # its own images (file names carry the global image index) and the PSNR reduced at the end (splitting a
+        # batch of one left N - 1 GPUs idle).  Either way an image's result does not depend on the rank count: its noise is a
+        # function of (seed, batch index, image index in the batch) only.
+        deal = world > 1 and config.sampling.batch_size < world
+        philox = os.environ.get("DDNM_NOISE") != "torch"      # in-kernel Philox draws (default) | ATen tape (BatchNoise)
         for bi, (x_orig, classes) in enumerate(loader):
-            # every rank sees the same batch (same loader seed); rank r restores images [lo, hi) of it
-            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
             b = x_orig.shape[0]
-            lo, hi = ddist.shard_range(b, rank, world)
-            noise = BatchNoise(args.seed, bi, b, (C, S, S), lo, hi, self.device)
-            y = A_funcs.A(x_orig)                # the whole batch: operators are cheap, and rank 0 needs A^+ y of all
+            if deal and bi % world != rank:
+                idx_so_far += b
+                continue
+            # (split mode: every rank sees the same batch -- same loader seed; rank r restores images [lo, hi) of it)
+            x_orig = data_transform(config, x_orig.to(self.device)).contiguous()
+            lo, hi = (0, b) if deal else ddist.shard_range(b, rank, world)
+            writer = deal or rank == 0
+            if philox:
+                # no ATen RNG launch in the loop, nothing drawn for other ranks' images: key = (seed, batch), counter =
+                # (element, iteration, image index in the batch); bench.py times this path
+                noise = ops.PhiloxNoise(_mix64(args.seed, bi), image_base=lo)
+                x = noise.tensor(ops.PhiloxNoise.XT_ITER, torch.empty(max(hi - lo, 1), C, S, S, device=self.device))[:hi - lo]
+            else:
+                noise = BatchNoise(args.seed, bi, b, (C, S, S), lo, hi, self.device)
+                x = noise.x_T()
+            y = A_funcs.A(x_orig)                # the whole batch: operators are cheap, and the writer needs A^+ y of all
             if args.add_noise:
-                y = y + noise.draw(tuple(y.shape)) * sigma_y
-            if rank == 0:
+                if philox:
+                    y = y + ops.PhiloxNoise(_mix64(args.seed, bi) ^ 0x5DEECE66D, 0).tensor(0, y.reshape(b, -1)).reshape(y.shape) * sigma_y
+                else:
+                    y = y + noise.draw(tuple(y.shape)) * sigma_y
+            if writer:
                 Apy = A_funcs.A_pinv(y).view(b, C, S, S)
                 if args.deg[:6] == "deblur":
                     Apy = y.view(b, C, S, S)
@@ -391,7 +419,6 @@ class Diffusion(object):
                                os.path.join(args.image_folder, f"Apy/Apy_{idx_so_far + i}.png"))
                     save_image(ops.finalize_psnr(x_orig[i:i + 1])[0][0],
                                os.path.join(args.image_folder, f"Apy/orig_{idx_so_far + i}.png"))
-            x = noise.x_T()
             if hi > lo:
                 y_loc = y.reshape(b, -1)[lo:hi].contiguous()
                 with torch.no_grad():
@@ -404,8 +431,8 @@ class Diffusion(object):
                 x_loc = xs[0]
             else:
                 x_loc = x                    # empty shard (fewer images than ranks): takes part in the gather only
-            x_all = ddist.gather_images(x_loc, n_total=b)      # the path's single collective (one per batch)
-            if rank == 0:
+            x_all = x_loc if deal else ddist.gather_images(x_loc, n_total=b)      # the path's single collective (one per batch)
+            if writer:
                 img, psnr = ops.finalize_psnr(x_all.contiguous(), x_orig)
                 for j in range(b):
                     save_image(img[j], os.path.join(args.image_folder, f"{idx_so_far + j}_{0}.png"))
@@ -413,6 +440,8 @@ class Diffusion(object):
                 n_done += b
                 print("PSNR: %.2f" % (psnr_sum / n_done))
             idx_so_far += b
+        if deal:
+            psnr_sum, n_done = ddist.reduce_sum(psnr_sum, self.device), int(ddist.reduce_sum(n_done, self.device))
         if rank == 0:
             print("Total Average PSNR: %.2f" % (psnr_sum / max(n_done, 1)))
             print("Number of samples: %d" % n_done)

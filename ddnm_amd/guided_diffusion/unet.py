@@ -324,7 +324,7 @@ class UNetModel:
 
     def _gn(self, x0, x1, name, film=None):
         if x1 is None and isinstance(x0, ops.Act) and x0.gn is not None and x0.gn[2] == name \
-                and x0.gn[3].generation == x0.gn[4] and os.environ.get("DDNM_NO_FUSED_FIN") != "1":
+                and x0.gn[3].generation == x0.gn[4]:
             # already finalized by the launch that produced x0 (its split-K reduction pass), and no other GroupNorm has
             # written the shared scale / shift buffers since (generation counter): no launch here
             sc, sh = x0.gn[0], x0.gn[1]
@@ -409,7 +409,7 @@ class UNetModel:
     # ------------------------------------------------------------------ fp16-activation forward (csrc/conv16.hip)
     def _conv3x3_16(self, key, cout, x0, x1, gn, silu=True, **kw):
         """3x3 convolution of act(concat(x0, x1)) on ddnm_conv16 with the GroupNorm affine + swish and the concat fused
-        into its loader (DDNM_H16_PREPASS=1: operand written once by ops.gn_apply16 instead); images too small for a
+        into its loader; images too small for a
         pixel tile (8x8) go through im2col + one GEMM with K = 9*Cin."""
         w16 = self.w[key + ".h16"]
         B, H, W, _ = x0.t.shape
@@ -417,10 +417,6 @@ class UNetModel:
         ups = kw.get("ups", False)
         Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
         if ops.conv16_supported(B, Ho, Wo, cin, cout, 3, ups=ups):
-            pre = os.environ.get("DDNM_H16_PREPASS", "")
-            if pre == "1" or (pre.startswith("auto") and gn is not None and cout >= int(pre[4:] or 1024) and Ho * Wo <= 1024):
-                a = x0.t if (gn is None and x1 is None) else ops.gn_apply16(x0, x1, gn, silu)
-                return ops.conv16(a, w16, cout, 3, **kw)
             return ops.conv16(x0, w16, cout, 3, src1=x1, gn=gn, gn_silu=silu, **kw)
         assert not ups and kw.get("skip") is None
         col = ops.im2col16(x0, x1, gn, silu)
@@ -510,9 +506,6 @@ class UNetModel:
         gn = self._gn(h, None, "out.0")
         B, H, W, _ = h.t.shape
         if W % 32 == 0 and H % 8 == 0:
-            if os.environ.get("DDNM_H16_PREPASS") == "1":
-                return ops.conv16_out(ops.gn_apply16(h, None, gn, True), w["out.2.weight.h16"], self.out_channels,
-                                      bias=w["out.2.bias"])
             return ops.conv16_out(h, w["out.2.weight.h16"], self.out_channels, bias=w["out.2.bias"], gn=gn, gn_silu=True)
         # images narrower than one 32-pixel output tile (reduced test nets): the exact-fp32 kernel on the fp16 operand
         a = ops.gn_apply16(h, None, gn, True)

@@ -55,11 +55,13 @@ def set_kernel_timer(t):
     _timer = t
 
 
-def max_launch_batch(per_image_bytes, margin=4):
+def max_launch_batch(per_image_bytes, margin=2):
     """Largest batch whose biggest activation stays `margin` times below the 2 GiB one convolution launch can address
     (32-bit byte offsets of the raw buffer descriptors, csrc/conv_common.h::conv_sizes_addressable): the models split a
     larger batch into chunks of this size INSIDE forward() instead of refusing it (the reference: "you may increase the
-    batch_size to accelerate evaluation", README.md:89)."""
+    batch_size to accelerate evaluation", README.md:89).  Margin 2 = half of the addressable limit (32 images for the celeba
+    `Model` and the fp16-activation ADM UNet at 256 x 256, 16 for the fp32 ADM UNet): the 32-image BASELINE configurations run
+    as ONE launch per layer (round 5's margin of 4 split them into two chunks plus a concat copy)."""
     return max(1, (1 << 31) // int(per_image_bytes) // margin)
 
 
@@ -206,7 +208,7 @@ def _f16_scratch(device, numel, slot=0):
 
 
 AMAX_N = 32          # include/ddnm_hip.h::DDNM_AMAX_N
-_S16_CHECK = _os.environ.get("DDNM_S16_CHECK") == "1"      # debug: assert finiteness after every split-fp16 launch (syncs)
+_S16_CHECK = False      # module attribute (debugging): assert finiteness after every split-fp16 launch (synchronises)
 
 
 def amax_bound(a0, a1=None):

@@ -436,14 +436,6 @@ typedef struct ddnm_step_scalars {
     uint32_t reserved_rng;
 } ddnm_step_scalars;
 
-/* ABI 6 -- the sr_bicubic step (BASELINE configs[1]; svd_ddnm.py:57-65 with SRConv, svd_operators.py:851-931) in two
- * launches: x0 = (xt - et*sqrt(1-at))/sqrt(at) (written out), R = Ae x0 Ae^T - y per (b, c) plane, xt' = sqrt(at') (x0 -
- * lambda Pe R Pe^T) + c1 noise + c2 et.  AeT [D][M] = Ae^T, PeT [M][D] = Pe^T (fp32, row-major); D = 256, M = 64 only
- * (DDNM_E_SHAPE otherwise: the caller keeps the GEMM route); noise NULL + rng_on = in-kernel draw. */
-int64_t ddnm_step_srconv_workspace_floats(int32_t B, int32_t C, int32_t D, int32_t M);
-int ddnm_step_srconv_f32(const float* xt, const float* et, int64_t et_bstride, const float* noise, const float* y,
-                         const float* AeT, const float* PeT, float* workspace, float* x0, float* xt_next, int32_t B,
-                         int32_t C, int32_t D, int32_t M, const ddnm_step_scalars* s, void* stream);
 
 /* out [B][chw] fp32 = the Philox draw described above (chw % 4 == 0) */
 int ddnm_randn_philox_f32(float* out, int32_t B, int64_t chw, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter,

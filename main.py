@@ -10,7 +10,8 @@ the device generator, and any exception inside the run is logged while the proce
 (main.py:164-170).  Multi-GPU: like the reference, which takes every visible GPU from the plain command through
 nn.DataParallel (guided_diffusion/diffusion.py:140,164,180), `python main.py ...` on a node with N > 1 visible GPUs
 re-executes itself as N ranks (one process per GPU, `torch.distributed.run`; DDNM_GPUS=n picks another count,
-DDNM_GPUS=1 stays in this process); an explicit `python -m torch.distributed.run --nproc-per-node N main.py ...`
+DDNM_GPUS=1 stays in this process; loader batches smaller than the rank count -- the shipped batch_size 1 -- are dealt whole
+to the ranks, larger ones are split by image and gathered); an explicit `python -m torch.distributed.run --nproc-per-node N main.py ...`
 works as before.
 
 `--path_y synthetic:N` (ours) replaces the dataset by N seeded uniform-noise images.
@@ -120,13 +121,27 @@ def prepare_image_folder(args, rank):
 
 
 def maybe_self_launch(argv):
-    """Plain `python main.py ...` with several visible GPUs: re-exec as one rank per GPU (does not return then)."""
+    """Plain `python main.py ...` with several visible GPUs: re-exec as one rank per GPU (does not return then).  The
+    arguments are parsed and the output-folder question is settled HERE, in the parent, before any rank exists: the
+    interactive Y/N prompt of the reference (main.py:112-135) keeps working, and a refused overwrite spawns nothing."""
     if "WORLD_SIZE" in os.environ or not torch.cuda.is_available():
         return
     ndev = torch.cuda.device_count()
     n = int(os.environ.get("DDNM_GPUS", "0")) or ndev
     if n <= 1:
         return
+    parser = argparse.ArgumentParser(add_help=False)
+    for names, kw in FLAGS:
+        parser.add_argument(*names, **kw)
+    pre, _ = parser.parse_known_args(sys.argv[1:] if argv is None else argv)
+    pre.image_folder = os.path.join(pre.exp, "image_samples", pre.image_folder)
+    extra = []
+    if os.path.exists(pre.image_folder) and not pre.ni:
+        answer = input(f"Image folder {pre.image_folder} already exists. Overwrite? (Y/N)")
+        if answer.upper() != "Y":
+            print("Output image folder exists. Program halted.")
+            sys.exit(0)
+        extra = ["--ni"]                      # the answer travels to the ranks
     if n > ndev and os.environ.get("DDNM_DIST_BACKEND") != "gloo":      # gloo: the 1-GPU test mode, ranks share the device
         sys.stderr.write(f"[main] DDNM_GPUS={n} but only {ndev} GPU(s) are visible\n")
         sys.exit(2)
@@ -136,7 +151,7 @@ def maybe_self_launch(argv):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv) + extra
     sys.exit(subprocess.call(cmd))
 
 

@@ -27,3 +27,11 @@ def hip():
     from ddnm_amd import _lib
     assert torch.cuda.is_available(), "gpu-marked test running without a GPU"
     return _lib.lib()
+
+
+@pytest.fixture(autouse=True)
+def _main_stays_in_process(monkeypatch):
+    """`main.main([...])` called in-process must not re-execute itself as one rank per visible GPU on a multi-GPU host
+    (ADVICE r5); the tests of the self-launch set DDNM_GPUS themselves, in the environment of the child they start."""
+    if "DDNM_GPUS" not in os.environ:
+        monkeypatch.setenv("DDNM_GPUS", "1")

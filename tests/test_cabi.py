@@ -38,7 +38,7 @@ def test_prototypes_match_header():
 
 def test_version_and_error_strings(lib):
     from ddnm_amd import _lib
-    assert lib.ddnm_version() == _lib.ABI_VERSION == 6
+    assert lib.ddnm_version() == _lib.ABI_VERSION == 7
     assert b"shape" in lib.ddnm_error_string(-2)
     assert b"bad argument" in lib.ddnm_error_string(-1)
     assert lib.ddnm_error_string(0) == b"success"
@@ -149,3 +149,65 @@ def test_conv_entry_points_refuse_tensors_beyond_32bit_offsets(lib):
         d.B, d.Hin, d.Win, d.C0, d.Cout, d.ksize, d.stride, d.pad, d.Ho, d.Wo = 256, 256, 256, 128, 128, 3, 1, 1, 256, 256
         d.acc_scale = 1.0
         assert fn(ctypes.byref(d), None) == -2, fn.__name__                # 2^31 output elements exactly: refused
+
+
+# ---- INTEGRATION.md section 2 is executable: the worked ctypes stub a maintainer would copy --------------------------------
+def _integration_blocks():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    return re.findall(r"```python\n(.*?)```", text, flags=re.S)
+
+
+def test_integration_md_stub_setup_block_runs_against_the_built_library(lib):
+    """The first python block of INTEGRATION.md (struct mirror, version / size assertions, prototypes) is EXECUTED here
+    against the library the build produced: a document that falls behind include/ddnm_hip.h (round 5: a 24-byte
+    ddnm_step_scalars against the 48-byte ABI-6 struct) fails this test."""
+    blocks = _integration_blocks()
+    assert len(blocks) >= 2 and "class StepScalars" in blocks[0] and "ddnm_step_sr_avgpool_f32(" in blocks[1]
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)                         # the block loads "ddnm_amd/libddnm_hip.so" relative to the repository root
+    try:
+        exec(compile(blocks[0], "INTEGRATION.md[block 0]", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    doc = ns["StepScalars"]
+    from ddnm_amd._lib import PROTOTYPES, StepScalars
+    assert ctypes.sizeof(doc) == ctypes.sizeof(StepScalars) == lib.ddnm_sizeof(3) == 48
+    assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in StepScalars._fields_]
+    # the prototype the document declares is the one the loader uses (the struct pointer aside: two mirror classes)
+    restype, argtypes = PROTOTYPES["ddnm_step_sr_avgpool_f32"]
+    fn = ns["lib"].ddnm_step_sr_avgpool_f32
+    assert fn.restype is restype and len(fn.argtypes) == len(argtypes)
+    assert [a for a in fn.argtypes if a is not ctypes.POINTER(doc)] == [a for a in argtypes if a is not ctypes.POINTER(StepScalars)]
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_call_block_runs_on_the_gpu():
+    """Both blocks executed as written, on device tensors; the result must be the oracle's step (svd_ddnm.py:57-65 with
+    the average-pooling operator)."""
+    import torch
+    from oracle import operators
+    blocks = _integration_blocks()
+    torch.manual_seed(0)
+    n, eta = 2, 0.85
+    at, at_next = torch.tensor(0.37), torch.tensor(0.52)
+    xt, et = torch.randn(n, 3, 256, 256, device="cuda"), torch.randn(n, 3, 256, 256, device="cuda")
+    op = operators.SuperResolution(3, 256, 4)
+    y = op.A(torch.rand(n, 3, 256, 256) * 2 - 1).cuda().contiguous()
+    x0_t, xt_next = torch.empty_like(xt), torch.empty_like(xt)
+    ns = dict(torch=torch, at=at, at_next=at_next, eta=eta, xt=xt, et=et, y=y, x0_t=x0_t, xt_next=xt_next, n=n)
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        torch.manual_seed(7)
+        exec(compile(blocks[0] + "\n" + blocks[1], "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    noise = ns["noise"]
+    x0 = (xt.cpu() - et.cpu() * (1 - at).sqrt()) / at.sqrt()
+    x0h = x0 - op.A_pinv(op.A(x0) - y.cpu().reshape(n, -1)).reshape(x0.shape)
+    c1, c2 = (1 - at_next).sqrt() * eta, (1 - at_next).sqrt() * (1 - eta ** 2) ** 0.5
+    want = at_next.sqrt() * x0h + c1 * noise.cpu() + c2 * et.cpu()
+    assert ((x0_t.cpu() - x0).norm() / x0.norm()).item() < 1e-6
+    assert ((xt_next.cpu() - want).norm() / want.norm()).item() < 2e-6

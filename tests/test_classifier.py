@@ -133,7 +133,7 @@ def test_fp16_activation_engine_tracks_the_fp32_engine_off_the_golden_point(hip,
 def test_grouped_pass_shares_the_timestep_independent_prefix(hip, monkeypatch, kind, n, G):
     """A grouped guidance pass is G copies of the same n images with G timesteps (svd_ddnm.py::_GuidanceAhead).  The input
     convolution and the first ResBlock's in_layers do not see the timestep, so the fp16-activation engine evaluates them once
-    for the n distinct images (`replicas=G`) -- bit-identical to evaluating every copy (DDNM_CLS_SHARE_PREFIX=0), and each
+    for the n distinct images (`replicas=G`) -- bit-identical to evaluating every copy (classifier.SHARE_PREFIX = False), and each
     copy equals the un-grouped call at its own timestep."""
     from ddnm_amd.guided_diffusion.classifier import make_cond_fn
     cc = weights.classifier_config(**KINDS[kind])
@@ -147,7 +147,8 @@ def test_grouped_pass_shares_the_timestep_independent_prefix(hip, monkeypatch, k
     tg = torch.tensor([float(10 + 240 * k) for k in range(G) for _ in range(n)]).cuda()
     yg = torch.full((G * n,), 951).cuda()
     shared = fn(xg, tg, yg, replicas=G)
-    monkeypatch.setenv("DDNM_CLS_SHARE_PREFIX", "0")
+    from ddnm_amd.guided_diffusion import classifier as _cl
+    monkeypatch.setattr(_cl, "SHARE_PREFIX", False)
     plain = fn(xg, tg, yg, replicas=G)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(shared).all()) and torch.equal(shared, plain)
@@ -339,7 +340,7 @@ def test_guidance_stream_equals_serial_order(hip, monkeypatch):
     model = create_model(**vars(cfg.model))
     model.load_state_dict(sd)
     outs = {}
-    monkeypatch.setenv("DDNM_CLS_PAIR", "0")        # step-by-step evaluation: the launches of the serial order
+    monkeypatch.setenv("DDNM_CLS_GROUP", "1")       # step-by-step evaluation: the launches of the serial order
     for mode in ("1", "0", "1"):
         monkeypatch.setenv("DDNM_CLS_OVERLAP", mode)
         xs, x0s = ddnm_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, cls_fn=make_cond_fn(clf, 2.0),
@@ -354,7 +355,7 @@ def test_guidance_stream_equals_serial_order(hip, monkeypatch):
         assert torch.equal(u, v) and torch.equal(u, w)
     # default mode: the guidance terms of two consecutive steps in ONE pass over [x; x] (round 4).  Same arithmetic per
     # sample; a batch of 2n picks other split-K plans than n, i.e. another fp32 summation order
-    monkeypatch.setenv("DDNM_CLS_PAIR", "1")
+    monkeypatch.delenv("DDNM_CLS_GROUP")
     monkeypatch.setenv("DDNM_CLS_OVERLAP", "1")
     xs, x0s = ddnm_diffusion(x_T.cuda(), model, cases.betas().cuda(), 0.85, op, y, cls_fn=make_cond_fn(clf, 2.0),
                              classes=None, config=cfg, noise=[n.cuda() for n in tape], return_cpu=False)

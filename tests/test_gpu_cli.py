@@ -140,7 +140,8 @@ def _run_cli(tmp_path, nproc, folder, port):
 def test_two_ranks_shard_every_batch_and_match_one_rank(hip, tmp_path):
     """The product CLI under torchrun with 2 ranks (both on this one GPU, gloo backend): every batch of 2 images
     (and the last, ragged batch of 1) is split by image index, ONE gather per batch, rank 0 writes the PNGs -- and the
-    files are those of the 1-rank run (noise is drawn per batch for the whole batch, so sharding does not change it)."""
+    files are those of the 1-rank run (an image's noise is a function of (seed, batch, image index) only -- in-kernel Philox
+    draws -- so sharding does not change it)."""
     import socket
     from PIL import Image
     _reduced_yaml(tmp_path)
@@ -153,6 +154,15 @@ def test_two_ranks_shard_every_batch_and_match_one_rank(hip, tmp_path):
         return p
     out1 = _run_cli(tmp_path, 1, "one", port())
     out2 = _run_cli(tmp_path, 2, "two", port())
+    # three ranks, loader batches of two: a batch SMALLER than the rank count is dealt whole (round-robin), every rank
+    # writes its own images and the PSNR is reduced -- the shipped configs' batch_size 1 on a multi-GPU node
+    out3 = _run_cli(tmp_path, 3, "three", port())
+    assert "Number of samples: 5" in out3 and out3.count("Total Average PSNR") == 1
+    d1, d3 = tmp_path / "exp" / "image_samples" / "one", tmp_path / "exp" / "image_samples" / "three"
+    assert sorted(p.name for p in d3.glob("*.png")) == [f"{i}_0.png" for i in range(5)]
+    assert len(list((d3 / "Apy").glob("*.png"))) == 10
+    for i in range(5):          # whole batches: the same launch shapes as the 1-rank run, the same noise -> the same bytes
+        assert (d1 / f"{i}_0.png").read_bytes() == (d3 / f"{i}_0.png").read_bytes(), i
     assert "Number of samples: 5" in out1 and "Number of samples: 5" in out2
     assert out1.count("Total Average PSNR") == 1 and out2.count("Total Average PSNR") == 1     # rank 0 only
     psnr = lambda o: float(o.split("Total Average PSNR:")[1].split()[0])                        # noqa: E731
@@ -244,6 +254,8 @@ def test_bench_eight_ranks_on_one_gpu(hip):
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["backend"] == "gloo"
+    # the first real N > 1 record explains itself: start-up, the single collective and the steady state are separate figures
+    assert line["startup_s"] > 0 and line["gather_ms"] > 0 and line["gather_ms"] < line["ms_per_step"]
     assert line["config"]["global_batch"] == 64 and line["scaling"] == "weak" and line["value"] > 0
     w = line["workloads"]
     assert w["c3"]["scaling"] == "strong" and w["c3"]["config"]["global_batch"] == 32 and w["c3"]["config"]["per_gpu_batch"] == 4

@@ -109,46 +109,57 @@ def test_split_kernel_is_at_least_as_close_to_fp64_as_the_fp32_kernel(case):
     assert ((a16.t - a32.t).norm() / a32.t.norm()).item() < 1.5e-6
 
 
-# DDNM_S16_W4=1: launches with >= 512 tiles and no split-K run the 4-wave form, two workgroups per CU (round 5):
+# Launches of >= 2 tiles per CU (>= 512 tiles, no split-K, no fused shortcut) run the PERSISTENT form of the kernel
+# (csrc/conv_s16_persist.hip, round 6): tiles walked by one workgroup per CU, the next tile's halo / weights prefetched in
+# the last chunk, the epilogue's stores and residual loads spread over the neighbouring chunks.
 # B, C0, C1, Cout, H, ups, gn, res, skip, badd
-W4_CASES = [
-    (8, 128, 0, 128, 128, 0, 1, 1, 0, 1),     # 512 tiles: GroupNorm + swish, temb addend, residual, 4 chunks
-    (2, 128, 128, 128, 256, 0, 1, 0, 1, 0),   # 256 x 256: concat of two sources + fused 1x1 shortcut
+PERSIST_CASES = [
+    (8, 128, 0, 128, 128, 0, 1, 1, 0, 1),     # 512 tiles (2 per CU): GroupNorm + swish, temb addend, residual, 4 chunks
+    (2, 128, 128, 128, 256, 0, 1, 0, 0, 0),   # 256 x 256: concat of two sources, 8 chunks
     (2, 128, 0, 128, 128, 1, 0, 0, 0, 0),     # Upsample conv (raw operand: the operand-scale instance), output 256 x 256
-    (4, 160, 0, 256, 128, 0, 1, 1, 0, 0),     # Cin = 5 chunks, two channel tiles
-    (9, 32, 0, 128, 128, 0, 0, 0, 0, 0),      # ONE chunk (no chunk hand-over), ragged batch
-    (8, 128, 0, 128, 64, 0, 1, 1, 0, 0),      # 128 tiles only: stays on the 8-wave kernel either way (control)
+    (4, 160, 0, 256, 128, 0, 1, 1, 0, 1),     # Cin = 5 chunks, two channel tiles (the weight stream changes between tiles)
+    (3, 64, 0, 128, 256, 0, 1, 1, 0, 0),      # TWO chunks (FIRST directly followed by LAST), 768 tiles: 3 per workgroup
+    (9, 96, 0, 128, 128, 0, 0, 0, 0, 0),      # ragged: 576 tiles over 256 workgroups (2 or 3 each), raw operand, no residual
+    (5, 128, 0, 128, 128, 0, 1, 0, 0, 1),     # 320 tiles: NOT eligible, stays on the one-tile kernel either way (control)
 ]
 
 
-@pytest.mark.parametrize("case", W4_CASES)
-def test_four_wave_split_kernel_is_fp32_grade(case):
-    """conv3x3_halo_f16_kernel<2, 2, 4, 2, .., W4>: same arithmetic as the 8-wave split kernel -- the result must be
-    BIT-IDENTICAL to it (same products, same summation order per output): this process runs the default 8-wave kernel, a
-    child process with DDNM_S16_W4=1 the 4-wave one; fp32 grade against fp64, GroupNorm partials included."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
+@pytest.mark.parametrize("case", PERSIST_CASES)
+def test_persistent_split_kernel_equals_the_one_tile_kernel(case):
+    """conv3x3_s16_persist_kernel: same products, same summation order, same epilogue expression as the one-tile kernel --
+    output AND GroupNorm partials must be BIT-IDENTICAL to it (`one_tile=True` = ddnm_conv_desc::flags & DDNM_CONV_ONE_TILE
+    selects the one-tile kernel for the same descriptor); fp32 grade against fp64 on top."""
+    from ddnm_amd import ops
     B, C0, C1, Cout, H, ups, gn, res, skip, badd = case
     t = _make(*case, seed=11)
-    e = _errors(t)
-    rel32, s32, a32 = e[False]
-    rel16, s16, a16 = e[True]
-    assert rel16 < 8e-7, (rel16, rel32)
-    assert rel16 <= 1.25 * rel32 + 2e-8, (rel16, rel32)
-    assert s16 < 2e-6 and a16.stats is not None
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory() as td:
-        code = (f"import sys, torch; sys.path.insert(0, {root!r}); from tests import test_gpu_s16 as T\n"
-                f"t = T._make(*{case!r}, seed=11); a, _ = T._run(t, True); torch.cuda.synchronize()\n"
-                f"torch.save((a.t.cpu(), a.stats.cpu()), {td!r} + '/o.pt')\n")
-        env = dict(os.environ, DDNM_S16_W4="1", PYTHONPATH=root)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        ot, ost = torch.load(td + "/o.pt")
-    assert torch.equal(a16.t.cpu(), ot), "4-wave and 8-wave split kernels must agree bit for bit"
-    assert torch.equal(a16.stats.cpu(), ost) or (a16.stats.cpu() - ost).abs().max() <= 1e-3 * ost.abs().max()
+    if not gn:
+        t["amax"] = ops.amax_bound(t["a"], t["b"])
+    y = _ref64(t)
+    outs = {}
+    for one_tile in (True, False):
+        scale = ops.s16_weight_scale(t["w"])
+        s16 = (ops.pack_conv_weight_s16(t["w"], scale), scale, None)
+        a = ops.conv2d(t["a"], ops.pack_conv_weight(t["w"]), Cout, 3, src1=t["b"], bias=t["bias"], res=t["r"],
+                       gn=None if t["sc"] is None else (t["sc"], t["sh"]), gn_silu=True, badd=t["badd"],
+                       badd_stride=(Cout if t["badd"] is not None else 0), ups=bool(ups), emit_stats=True, weight_s16=s16,
+                       raw_amax=t["amax"], one_tile=one_tile)
+        torch.cuda.synchronize()
+        outs[one_tile] = (a.t.clone(), a.stats.clone(), a.tiles)
+    o = outs[False][0].double()
+    assert ((o - y).norm() / y.norm()).item() < 8e-7
+    st = outs[False][1].view(B, outs[False][2], -1, 2).double().sum(1)
+    s1, s2 = o.sum((1, 2)), (o * o).sum((1, 2))
+    assert ((st[..., 0] - s1).abs().max() / s1.abs().max()).item() < 2e-6
+    assert ((st[..., 1] - s2).abs().max() / s2.abs().max()).item() < 2e-6
+    assert outs[True][2] == outs[False][2]
+    assert torch.equal(outs[True][0], outs[False][0]), "persistent and one-tile split kernels must agree bit for bit"
+    assert torch.equal(outs[True][1], outs[False][1]), "GroupNorm partials of the two kernels must agree bit for bit"
+    # repeated launches are bit-identical (no atomics, fixed orders, a deterministic request stream)
+    a2 = ops.conv2d(t["a"], ops.pack_conv_weight(t["w"]), Cout, 3, src1=t["b"], bias=t["bias"], res=t["r"],
+                    gn=None if t["sc"] is None else (t["sc"], t["sh"]), gn_silu=True, badd=t["badd"],
+                    badd_stride=(Cout if t["badd"] is not None else 0), ups=bool(ups), emit_stats=True, weight_s16=s16,
+                    raw_amax=t["amax"])
+    assert torch.equal(a2.t, outs[False][0]) and torch.equal(a2.stats, outs[False][1])
 
 
 @pytest.mark.parametrize("wscale,ascale", [(40.0, 1.5), (3e-5, 1.5), (0.05, 300.0), (0.05, 8000.0), (0.05, 0.15)])

@@ -122,38 +122,3 @@ def test_sharded_batch_matches_unsharded(hip):
     for lo in (0, 2):
         part, _, _ = run_engine(cfg, sd, "sr_averagepooling", x_T[lo:lo + 2], [n[lo:lo + 2] for n in tape], y[lo:lo + 2])
         assert rel(part, full[lo:lo + 2]) < 1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("B", [1, 3])
-def test_srconv_two_launch_step_equals_the_gemm_route(hip, monkeypatch, B):
-    """The headline step in two launches (csrc/sr_step.hip: x0 + Ae X Ae^T partials | R, Pe R Pe^T, DDIM update) against the
-    six-launch GEMM route (the default: it measured 0.3 % faster) and against an fp64 evaluation of svd_ddnm.py:57-65 with
-    the operator's own Ae / Pe; 6-channel `et` view (learn_sigma heads) included."""
-    from ddnm_amd import ops
-    from tests.helpers import engine_operator
-    d = 256
-    op = engine_operator("sr_bicubic", d)
-    g = torch.Generator().manual_seed(12)
-    xt = torch.randn(B, 3, d, d, generator=g).cuda()
-    et6 = torch.randn(B, 6, d, d, generator=g).cuda()
-    et = et6[:, :3]
-    noise = torch.randn(B, 3, d, d, generator=g).cuda()
-    y = torch.randn(B, 3 * 64 * 64, generator=g).cuda()
-    s = ops.step_scalars(torch.tensor(0.37), torch.tensor(0.52), 0.85)
-    res = {}
-    for route in ("fused", "gemm"):
-        monkeypatch.setenv("DDNM_SR_STEP_FUSED", "0" if route == "gemm" else "1")
-        x0, out = torch.empty_like(xt), torch.empty_like(xt)
-        op.ddnm_step(xt, et, noise, y, s, x0, out)
-        torch.cuda.synchronize()
-        res[route] = (x0.clone(), out.clone())
-    assert torch.equal(res["fused"][0], res["gemm"][0])                       # x0: the same elementwise arithmetic
-    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()   # noqa: E731
-    assert rel(res["fused"][1], res["gemm"][1]) < 2e-6
-    Ae, Pe = op.Ae.double().cpu(), op.Pe.double().cpu()
-    x0 = ((xt.double().cpu() - et.double().cpu() * s.sqrt_1m_at) / s.sqrt_at)
-    R = Ae @ x0 @ Ae.T - y.double().cpu().reshape(B, 3, 64, 64)
-    want = (x0 - Pe @ R @ Pe.T) * s.sqrt_at_next + noise.double().cpu() * s.c1 + et.double().cpu() * s.c2
-    assert rel(res["fused"][1].cpu(), want) < 2e-6
-    assert rel(res["fused"][1].cpu(), want) <= 2.0 * rel(res["gemm"][1].cpu(), want) + 1e-7

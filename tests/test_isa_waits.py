@@ -88,3 +88,56 @@ def test_conv16_k_loops_issue_only_lds_dma(tmp_path):
         assert n_reg == 0, f"{name}: {n_reg} register load(s) inside a K loop"
         allowed = {0} if grp[key] is None else {0, grp[key], 2 * grp[key]}
         assert set(imm) <= allowed, (name, imm, allowed)
+
+
+# ---- persistent split-fp16 kernel (round 6): all-paths replay over the control-flow graph -------------------------------
+def _p_wait(kind, tap, has_res, ascale):
+    """Python restatement of conv_s16_persist.hip::p_wait (kinds: 0 MID, 1 LAST, 2 FIRST)."""
+    BR, HR, HSPLIT = 2, 6, 3
+    spread = lambda t: 10 if t == 0 else (9 if t <= 6 else 0)        # noqa: E731
+
+    def extra(t):
+        if kind == 2:
+            return spread(t) + (1 if t == 0 else 0)
+        if kind == 1:
+            return ((4 + (1 if ascale else 0)) if t == 0 else 0) + (spread(t) if has_res else 0)
+        return 0
+    base = BR + HSPLIT + 2 if tap in (1, 2) else (BR + HR - HSPLIT if tap in (4, 5) else BR)
+    return base + (extra(tap - 1) if tap >= 1 else 0) + (extra(tap - 2) if tap >= 2 else 0)
+
+
+def test_persistent_kernel_waits_match_the_issue_order_on_every_path(tmp_path):
+    """conv3x3_s16_persist_kernel<ASCALE, HAS_RES>: tile loop, three chunk kinds, an inner loop and exec-mask branches --
+    every counted wait in front of a barrier is checked by walking back from it along EVERY path of the kernel's CFG: the
+    requests met up to the youngest request of the awaited weight tile must equal the immediate on all of them (deferred
+    stores, residual / bias / bound loads and the statistics store included), and the immediates are the source's table."""
+    asm = isa_waits.compile_isa(os.path.join(CSRC, "conv_s16_persist.hip"), str(tmp_path / "p.s"))
+    res = isa_waits.analyse_cfg(asm, r"conv3x3_s16_persist_kernel", depth=2, group_size=2)
+    assert len(res) == 4, list(res)
+    for name, waits in res.items():
+        ascale, has_res = "ILb1E" in name, ("ELb1EEv" in name)
+        assert len(waits) == 27, (name, len(waits))                 # 3 chunk kinds x 9 taps, each exactly once in the code
+        for n, found, line in waits:
+            assert found == [n], f"{name}: wait vmcnt({n}) at line {line}: requests behind the awaited tile on the paths = {found}"
+        want = sorted(_p_wait(kind, tap, has_res, ascale) for kind in (0, 1, 2) for tap in range(9))
+        assert sorted(n for n, _, _ in waits) == want, (name, sorted(n for n, _, _ in waits), want)
+
+
+def test_the_all_paths_check_fails_when_the_table_is_wrong(tmp_path):
+    """Mutation: one deferred store fewer at tap 0 than the table says (the FIRST chunk's waits of taps 1 / 2 then allow one
+    request too many in flight: the awaited weight tile may still be landing).  The replay must flag exactly those waits."""
+    src = open(os.path.join(CSRC, "conv_s16_persist.hip")).read()
+    old = "            for (int k = p_first_of(tap); k < p_first_of(tap + 1); ++k)\n                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv[k]), r_out,"
+    assert src.count(old) == 1
+    mut = src.replace(old, "            for (int k = p_first_of(tap) + (tap == 0 ? 1 : 0); k < p_first_of(tap + 1); ++k)\n"
+                           "                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv[k]), r_out,")
+    path = os.path.join(CSRC, "_mut_persist_test.hip")           # next to the headers it includes
+    try:
+        open(path, "w").write(mut)
+        asm = isa_waits.compile_isa(path, str(tmp_path / "m.s"))
+    finally:
+        os.remove(path)
+    res = isa_waits.analyse_cfg(asm, r"conv3x3_s16_persist_kernelILb0ELb0E", depth=2, group_size=2)
+    (waits,) = res.values()
+    bad = [(n, found) for n, found, _ in waits if found != [n]]
+    assert len(bad) == 2 and all(found == [n - 1] for n, found in bad), bad

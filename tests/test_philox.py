@@ -62,13 +62,12 @@ def test_engine_draw_matches_oracle_and_is_normal(hip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("deg,d", [("sr_averagepooling", 64), ("colorization", 64), ("inpainting", 64), ("denoising", 64),
                                    ("sr_bicubic", 64), ("cs_walshhadamard", 64), ("sr_bicubic", 256)])
-def test_in_kernel_draw_equals_the_tensor_path(hip, deg, d, monkeypatch):
+def test_in_kernel_draw_equals_the_tensor_path(hip, deg, d):
     """A step with noise = NULL + ddnm_step_scalars::rng_* gives the bits of the same step fed with the materialised draw."""
     from ddnm_amd import ops
     from oracle import cases
     from tests.helpers import engine_operator
-    B = 3                                  # (sr_bicubic at 256 x 256 with DDNM_SR_STEP_FUSED=1 = the two-launch step kernel)
-    monkeypatch.setenv("DDNM_SR_STEP_FUSED", "1" if d == 256 else "0")
+    B = 3
     op = engine_operator(deg, d)
     g = torch.Generator().manual_seed(3)
     x_orig = (torch.rand(B, 3, d, d, generator=g) * 2 - 1)

@@ -6,7 +6,7 @@
 #   the headline bench line (with the c3 / c4 / c5 workloads); summaries land in gpurun_out/ and the PMC json files are
 #   installed into profiles/ before the bench line is taken (bench.py binds them by source digest).
 # Every step runs under its own `timeout`: a faulting GPU once left rocprofv3 hanging for the whole remaining budget.
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 set +e
 python - <<'PY' || { echo 'GPU sanity check failed: not running the checkpoint on this box'; exit 3; }
 import torch
@@ -45,9 +45,6 @@ for T in c2 adm cls; do
   timeout -k 10 300 rocprofv3 --pmc $CA --kernel-trace -d $RAW/st_$T/pmc_stallA -o p --output-format csv -- $CMD > /root/repo/gpurun_out/pmc_${T}_A.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc $CB --kernel-trace -d $RAW/st_$T/pmc_stallB -o p --output-format csv -- $CMD > /root/repo/gpurun_out/pmc_${T}_B.log 2>&1
 done
-# the same MFMA-busy / clock counters on the 4-wave, two-workgroups-per-CU form of the headline kernel (A/B evidence for the
-# power limit: tools/experiments/HISTORY.md)
-DDNM_S16_W4=1 timeout -k 10 420 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $RAW/pmc_c2w4/pmc_mfma -o p --output-format csv -- python /root/repo/tools/forward_once.py 2 > /root/repo/gpurun_out/pmc_c2w4_mfma.log 2>&1
 # HBM-bound fringe: per-kernel bytes and durations
 timeout -k 10 300 rocprofv3 --kernel-trace -d $RAW/hbm/trace -o p --output-format csv -- python /root/repo/tools/hbm_kernels.py 3 > /root/repo/gpurun_out/hbm_trace.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $RAW/hbm/pmc_fetch -o p --output-format csv -- python /root/repo/tools/hbm_kernels.py 3 > /root/repo/gpurun_out/hbm_fetch.log 2>&1
@@ -55,20 +52,19 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/hbm/pmc_writ
 cd /root/repo
 python tools/prof_summary.py $(find $RAW/prof_cls -name "*.db" | head -1) gpurun_out/${R}_cls_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -22 gpurun_out/${R}_cls_kernel_stats.md
 python tools/prof_summary.py $(find $RAW/prof_cls32 -name "*.db" | head -1) gpurun_out/${R}_cls_b32_kernel_stats.md --after-marker finalize_psnr --forwards 3 > /dev/null; head -12 gpurun_out/${R}_cls_b32_kernel_stats.md
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true), false>' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/st_c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md | tail -7
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='(?:conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>|conv3x3_s16_persist_kernel)' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/st_c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md | tail -7
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM fp16 forwards at B=4 per pass (tools/adm_fwd.py)" python tools/pmc_stalls.py $RAW/st_adm gpurun_out/${R}_pmc_stalls_conv16.json gpurun_out/${R}_pmc_stalls_conv16.md | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_n128_kernel' PMC_PASSES="2 classifier-guidance evaluations at B=8 per pass (tools/cls_step.py)" python tools/pmc_stalls.py $RAW/st_cls gpurun_out/${R}_pmc_stalls_n128.json gpurun_out/${R}_pmc_stalls_n128.md | tail -5
 python tools/pmc_hbm_summary.py $RAW/hbm gpurun_out/hbm_kernels_algorithmic.json gpurun_out/${R}_hbm_kernels.json gpurun_out/${R}_hbm_kernels.md | tail -20
-python tools/pmc_clock.py $RAW/pmc_c2w4 'conv3x3_halo_f16_kernel<2, 2, 4, 2' > gpurun_out/${R}_pmc_w4_clock.txt 2>&1; cat gpurun_out/${R}_pmc_w4_clock.txt | tail -4
-cp gpurun_out/${R}_cls_kernel_stats.md gpurun_out/${R}_cls_b32_kernel_stats.md gpurun_out/${R}_pmc_stalls_*.json gpurun_out/${R}_pmc_stalls_*.md gpurun_out/${R}_hbm_kernels.json gpurun_out/${R}_hbm_kernels.md gpurun_out/${R}_pmc_w4_clock.txt profiles/ 2>/dev/null
+cp gpurun_out/${R}_cls_kernel_stats.md gpurun_out/${R}_cls_b32_kernel_stats.md gpurun_out/${R}_pmc_stalls_*.json gpurun_out/${R}_pmc_stalls_*.md gpurun_out/${R}_hbm_kernels.json gpurun_out/${R}_hbm_kernels.md profiles/ 2>/dev/null
 BDB=$(find $RAW/prof_bench -name "*.db" | head -1); ADB=$(find $RAW/prof_adm16 -name "*.db" | head -1)
 python tools/prof_summary.py $BDB gpurun_out/${R}_bench_kernel_stats.md > /dev/null; head -12 gpurun_out/${R}_bench_kernel_stats.md
 python tools/prof_summary.py $ADB gpurun_out/${R}_adm_fp16_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_adm_fp16_forward_kernel_stats.md
 python tools/prof_summary.py $(find $RAW/prof_c2fwd -name "*.db" | head -1) gpurun_out/${R}_celeba_forward_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -24 gpurun_out/${R}_celeba_forward_kernel_stats.md
 python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
 # dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., SRC16 = false,
-# SPLIT = true, ASCALE = either: the instance with the operand-range guard runs the launches that read a raw operand; W4 = false)
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true), false>' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+# SPLIT = true, ASCALE = either) and its persistent form
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='(?:conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>|conv3x3_s16_persist_kernel)' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
 B8DB=$(find $RAW/prof_adm16b8 -name "*.db" | head -1)
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=8 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16b8 gpurun_out/${R}_adm_pmc_conv16_b8.json gpurun_out/${R}_adm_pmc_conv16_b8.md $B8DB | tail -4

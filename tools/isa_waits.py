@@ -235,3 +235,115 @@ def dma_only_loops(asm, name_re):
                     imm.add(int(_VM.search(w.group(1)).group(1)))
         out[name] = (len(loops), n_dma, n_reg, sorted(imm))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# All-paths replay over the control-flow graph (round 6: conv_s16_persist.hip).  The persistent kernel's request stream runs
+# through a tile loop with three kinds of chunks (FIRST / MID / LAST), an inner loop (MID) and small exec-mask branches
+# (ds_write guards), so there is no single loop body to replay cyclically.  Here every counted wait in front of a barrier
+# is checked by walking BACKWARDS from it along EVERY path of the kernel's CFG until `depth` DMA groups (= `group_size`
+# LDS-DMA requests each) have been passed: the number of requests met on the way up to the youngest request of the awaited
+# group must equal the wait's immediate on all of them.
+def _blocks(lines):
+    """Basic blocks: (start, end_exclusive) index ranges, label -> block id, successors per block."""
+    starts = {0}
+    for i, l in enumerate(lines):
+        if _LABEL.match(l):
+            starts.add(i)
+        if _BRANCH.match(l) or l.startswith("\ts_endpgm"):
+            starts.add(i + 1)
+    starts = sorted(s for s in starts if s < len(lines))
+    blocks = [(s, (starts[k + 1] if k + 1 < len(starts) else len(lines))) for k, s in enumerate(starts)]
+    label_of = {}
+    for b, (s, e) in enumerate(blocks):
+        m = _LABEL.match(lines[s])
+        if m:
+            label_of[m.group(1)] = b
+    succ = [[] for _ in blocks]
+    for b, (s, e) in enumerate(blocks):
+        last = lines[e - 1] if e > s else ""
+        m = _BRANCH.match(last)
+        if last.startswith("\ts_endpgm"):
+            continue
+        if m and m.group(1) in label_of:
+            succ[b].append(label_of[m.group(1)])
+            if not last.startswith("\ts_branch"):         # conditional: falls through as well
+                if b + 1 < len(blocks):
+                    succ[b].append(b + 1)
+        elif b + 1 < len(blocks):
+            succ[b].append(b + 1)
+    return blocks, succ
+
+
+def _block_events(lines, s, e):
+    ev = []
+    for i in range(s, e):
+        l = lines[i]
+        if _REQ.match(l):
+            ev.append(("dma" if re.search(r"\blds\b", l) else "req", i))
+        elif l.startswith("\ts_barrier"):
+            ev.append(("barrier", i))
+        else:
+            w = _WAIT.match(l)
+            if w and _VM.search(w.group(1)):
+                ev.append(("wait", (int(_VM.search(w.group(1)).group(1)), "lgkmcnt(0)" in w.group(1), i)))
+    return ev
+
+
+def analyse_cfg(asm, name_re, depth, group_size):
+    """{kernel: [(N, sorted set of request counts found behind the awaited DMA group over all paths), ...]} for every
+    `s_waitcnt vmcnt(N) lgkmcnt(0)` (N > 0) that directly precedes an s_barrier."""
+    out = {}
+    for name, lines in kernels(asm).items():
+        if not re.search(name_re, name):
+            continue
+        blocks, succ = _blocks(lines)
+        pred = [[] for _ in blocks]
+        for b, ss in enumerate(succ):
+            for t in ss:
+                pred[t].append(b)
+        evs = [_block_events(lines, s, e) for (s, e) in blocks]
+        results = []
+        for b, ev in enumerate(evs):
+            for k, (kind, val) in enumerate(ev):
+                if kind != "wait" or not val[1] or val[0] == 0:
+                    continue
+                # directly in front of a barrier (same block, next event)
+                if k + 1 >= len(ev) or ev[k + 1][0] != "barrier":
+                    continue
+                found, seen = set(), set()
+                stack = [(b, k - 1, 0, 0, 0)]          # (block, event index, groups passed, dmas in the open group, behind)
+                while stack:
+                    st = stack.pop()
+                    if st in seen:
+                        continue
+                    seen.add(st)
+                    bb, idx, g, ing, behind = st
+                    done = False
+                    while idx >= 0:
+                        kd = evs[bb][idx][0]
+                        if kd == "dma":
+                            if ing == 0:                 # youngest request of a group: everything counted so far is behind it
+                                g += 1
+                                if g == depth:
+                                    found.add(behind)
+                                    done = True
+                                    break
+                            ing = (ing + 1) % group_size
+                            behind += 1
+                        elif kd == "req":
+                            behind += 1
+                        idx -= 1
+                    if done:
+                        continue
+                    if behind > 200:
+                        raise AssertionError(f"{name}: no DMA group within 200 requests of the wait at line {val[2]}")
+                    for pb in pred[bb]:
+                        stack.append((pb, len(evs[pb]) - 1, g, ing, behind))
+                    # (a path that reaches the kernel entry without `depth` groups does not exist for these kernels: the
+                    # prologue requests two weight tiles before the first wait)
+                results.append((val[0], sorted(found), val[2]))
+        out[name] = results
+    if not out:
+        raise AssertionError(f"no kernel matches {name_re}")
+    return out

@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +51,9 @@ struct Args {
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // GEO 0 = split (S), 1 = conv16-like (C)
-template <int GEO, int RUNG, int NWAVES>
+// PIPE = 1 (split geometry): explicit two-set fragment pipeline -- the 8 reads of k-step n + 1 are issued under the 12 MFMAs of
+// k-step n (the second k-step of a tap runs behind the NEXT tap's barrier), placed by sched_group_barrier
+template <int GEO, int RUNG, int NWAVES, int PIPE = 0>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void ladder_kernel(const Args p) {
     constexpr bool S = GEO == 0;
     constexpr int MT = S ? 2 : 4, NT = 2;
@@ -208,6 +211,65 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void ladder_kernel(const A
         }
     };
 
+    // ---- PIPE: two fragment sets
+    half8 fah[2][MT], fal[2][MT], fbh[2][NT], fbl[2][NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { fah[q][i] = rah[i]; fal[q][i] = ral[i]; }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { fbh[q][j] = rbh[j]; fbl[q][j] = rbl[j]; }
+    }
+    auto read_set = [&](auto SET, int tap, int ks, int buf, int hbuf) {
+        constexpr int q = decltype(SET)::value;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int tap_off = (ky * HWd + kx) * LDH + hbuf * MAXH * LDH;
+        const char* bf = Bs + buf * WTILE;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            fah[q][i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16);
+            fal[q][i] = *reinterpret_cast<const half8*>(Hs + a_off[i] + tap_off + ks * 16 + 32);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            fbh[q][j] = *reinterpret_cast<const half8*>(bf + ((b_frag ^ (ks << 5)) + j * 32 * 128));
+            fbl[q][j] = *reinterpret_cast<const half8*>(bf + ((b_frag ^ ((ks + 2) << 5)) + j * 32 * 128));
+        }
+    };
+    auto mfma_set = [&](auto SET) {
+        constexpr int q = decltype(SET)::value;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[q][i], fbh[q][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[q][i], fbl[q][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[q][i], fbh[q][j], acc[i][j], 0, 0, 0);
+    };
+    auto interleave = [&]() {            // 8 x (1 LDS read, 1 MFMA), then the remaining 4 MFMAs
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    };
+    auto pipe_tap = [&](int tap, int buf, int hbuf) {
+        read_set(std::integral_constant<int, 0>{}, tap, 0, buf, hbuf);
+        mfma_set(std::integral_constant<int, 1>{});       // the previous tap's second k-step
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+        read_set(std::integral_constant<int, 1>{}, tap, 1, buf, hbuf);
+        mfma_set(std::integral_constant<int, 0>{});
+        interleave();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     if (S && wave >= NWAVES / 2 && NWAVES == 8) __builtin_amdgcn_s_setprio(1);      // the product's static priority
     constexpr bool TILED = RUNG >= 6;
     const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
@@ -249,7 +311,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 4) void ladder_kernel(const A
                     if (tap == 6) stage_halo_part(hb ^ 1, HSPLIT, HR);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                mfma_tap(tap, NWB == 3 ? cur : wb2, RUNG >= 5 ? hb : 0);
+                if constexpr (PIPE == 1) pipe_tap(tap, cur, RUNG >= 5 ? hb : 0);
+                else mfma_tap(tap, NWB == 3 ? cur : wb2, RUNG >= 5 ? hb : 0);
                 wb2 ^= 1;
             }
             if constexpr (RUNG >= 5) hb ^= 1;
@@ -272,7 +335,7 @@ struct Bufs {
     float* src; char* weight; float* gn; half8* frag; float* out; unsigned long long* clk;
 };
 
-template <int GEO, int RUNG, int NWAVES>
+template <int GEO, int RUNG, int NWAVES, int PIPE = 0>
 static void run(const Bufs& b, const char* what) {
     constexpr bool S = GEO == 0;
     constexpr int MT = S ? 2 : 4, NT = 2, KSTEPS = S ? 2 : 4;
@@ -286,9 +349,9 @@ static void run(const Bufs& b, const char* what) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int warm = 40, reps = 40;                            // ~50 ms of warm-up: the clock settles to the power budget
-    for (int i = 0; i < warm; ++i) hipLaunchKernelGGL((ladder_kernel<GEO, RUNG, NWAVES>), dim3(grid), dim3(NWAVES * 64), 0, 0, a);
+    for (int i = 0; i < warm; ++i) hipLaunchKernelGGL((ladder_kernel<GEO, RUNG, NWAVES, PIPE>), dim3(grid), dim3(NWAVES * 64), 0, 0, a);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ladder_kernel<GEO, RUNG, NWAVES>), dim3(grid), dim3(NWAVES * 64), 0, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((ladder_kernel<GEO, RUNG, NWAVES, PIPE>), dim3(grid), dim3(NWAVES * 64), 0, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     if (hipGetLastError() != hipSuccess) { printf("launch failed: %s\n", what); exit(1); }
@@ -339,6 +402,11 @@ int main() {
     run<0, 4, 8>(b, "+ LDS-DMA weight tile per tap, 3 deep, counted vmcnt");
     run<0, 5, 8>(b, "+ halo: HBM loads, GroupNorm + swish, split, ds_write");
     run<0, 6, 8>(b, "the same as 8 tiles x 4 chunks per workgroup (launch shape)");
+    run<0, 2, 8, 1>(b, "PIPELINED rung 2: reads of k-step n+1 under the MFMAs of n");
+    run<0, 3, 8, 1>(b, "PIPELINED rung 3 (+ barrier)");
+    run<0, 4, 8, 1>(b, "PIPELINED rung 4 (+ LDS-DMA weights)");
+    run<0, 5, 8, 1>(b, "PIPELINED rung 5 (+ halo staging)");
+    run<0, 6, 8, 1>(b, "PIPELINED rung 6 (launch shape)");
     run<1, 1, 4>(b, "registers only");
     run<1, 1, 8>(b, "registers only");
     run<1, 2, 4>(b, "+ fragment ds_read_b128 (6 per 8 MFMAs)");

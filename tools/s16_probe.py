@@ -7,6 +7,9 @@
   * speed of both on the layer shapes of the celeba UNet.
 
     python tools/s16_probe.py [acc] [time]        # on the GPU box, product library
+
+(The build-variant ablations of rounds 3-5 -- `vtime`, -DDDNM_PROBE_* -- left with the probe sites they compiled: the product
+sources carry no wrong-result switches since round 6; `git show a920112:tools/s16_probe.py` has them.)
 """
 import ctypes
 import os
@@ -108,105 +111,8 @@ def run(t, split):
     return call
 
 
-VARIANTS = {
-    "base": [],
-    # a path instead of a flag list = another source file (e.g. a saved copy of an older kernel under tools/_build/)
-    "ks256": ["-DDDNM_F16_KS_TARGET=256"], "ks384": ["-DDDNM_F16_KS_TARGET=384"], "ks768": ["-DDDNM_F16_KS_TARGET=768"],
-    "nobar": ["-DDDNM_PROBE16_NO_TAP_BARRIER"],           # wrong results: no barrier per tap
-    "nobload": ["-DDDNM_PROBE16_NO_BLOAD"],               # wrong results: no weight loads
-    "nogn": ["-DDDNM_PROBE_NO_GN"],                       # wrong results: no GroupNorm + swish in the loader
-    "prio_mfma": ["-DDDNM_PROBE_SETPRIO_MFMA"],
-    "prio_half": ["-DDDNM_PROBE_SETPRIO_HALF"],
-    "nostore": ["-DDDNM_PROBE_NO_STORE"],
-}
-CSRC = os.path.join(ROOT, "ddnm_amd", "csrc")
-OUT = os.path.join(ROOT, "tools", "_build")
-
-
-def build_variant(name):
-    import subprocess
-    from ddnm_amd._lib import ConvDesc
-    so = os.path.join(OUT, f"libs16_{name}.so")
-    if not os.path.exists(so) or "--rebuild" in sys.argv:
-        extra = os.environ.get("S16_FLAGS", "").split()
-        v = VARIANTS[name]
-        src, flags = (os.path.join(ROOT, v), []) if isinstance(v, str) else (os.path.join(CSRC, "conv_igemm_f16.hip"), v)
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{ROOT}/include",
-                        f"-I{CSRC}"] + flags + extra + [src, "-o", so], check=True)
-    if "--build-only" in sys.argv:
-        return None
-    lib = ctypes.CDLL(so)
-    lib.ddnm_conv3x3_s16_f32.restype = ctypes.c_int32
-    lib.ddnm_conv3x3_s16_f32.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_void_p]
-    lib.ddnm_conv3x3_s16_workspace_floats.restype = ctypes.c_int64
-    lib.ddnm_conv3x3_s16_workspace_floats.argtypes = [ctypes.POINTER(ConvDesc)]
-    return lib
-
-
-def vtime(names):
-    """Raw-library timing of build variants of the split kernel (ablations give WRONG results on purpose)."""
-    from ddnm_amd._lib import ConvDesc
-    os.makedirs(OUT, exist_ok=True)
-    libs = {n: build_variant(n) for n in names}
-    if "--build-only" in sys.argv:
-        return
-    zero = os.environ.get("ZERO") == "1"
-    ws = torch.empty(128 << 20, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    shapes = SHAPES
-    if os.environ.get("SHAPES"):
-        shapes = [s for s in SHAPES if s[0] in os.environ["SHAPES"].split(",")]
-    print(f"{'shape':24s} " + " ".join(f"{n:>10s}" for n in libs) + "   (TFLOP/s, fp32-equivalent)" + (" ZERO data" if zero else ""))
-    for s in shapes:
-        name, B, C0, C1, Cout, H, ups, gn, res, skip = s
-        t = make(*s)
-        Ho = t["Ho"]
-        scale = ops.s16_weight_scale(*([t["w"]] + ([t["wsk"]] if skip else [])))
-        wp = ops.pack_conv_weight_s16(t["w"], scale)
-        wskp = ops.pack_conv_weight_s16(t["wsk"], scale) if skip else None
-        if zero:
-            for k in ("a", "b", "r", "sk"):
-                if t[k] is not None:
-                    t[k].zero_()
-            wp.zero_()
-        out = torch.empty(B, Ho, Ho, Cout, device=dev)
-        stats = torch.empty(B * 1024 * Cout * 2, device=dev)
-        d = ConvDesc()
-        d.src0, d.src1, d.weight, d.bias = t["a"].data_ptr(), (t["b"].data_ptr() if C1 else None), wp.data_ptr(), t["bias"].data_ptr()
-        d.res = t["r"].data_ptr() if res else None
-        d.gn_scale, d.gn_shift = (t["sc"].data_ptr(), t["sh"].data_ptr()) if gn else (None, None)
-        d.out, d.stats_out = out.data_ptr(), stats.data_ptr()
-        d.B, d.Hin, d.Win, d.C0, d.C1, d.Cout = B, Ho, Ho, C0, C1, Cout
-        d.ksize, d.stride, d.pad, d.Ho, d.Wo = 3, 1, 1, Ho, Ho
-        d.ups, d.gn_silu, d.acc_scale = ups, 1, 1.0 / scale
-        if skip:
-            d.skip0, d.skip_weight, d.SC0 = t["sk"].data_ptr(), wskp.data_ptr(), 64
-        d.workspace, d.workspace_floats = ws.data_ptr(), ws.numel()
-        flops = 2.0 * B * Ho * Ho * Cout * (9 * (C0 + C1) + (64 if skip else 0))
-        row = []
-        for n, lib in libs.items():
-            for _ in range(3):
-                rc = lib.ddnm_conv3x3_s16_f32(ctypes.byref(d), stream)
-                assert rc == 0, rc
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
-            e0.record()
-            for _ in range(reps):
-                lib.ddnm_conv3x3_s16_f32(ctypes.byref(d), stream)
-            e1.record()
-            torch.cuda.synchronize()
-            row.append(flops / (e0.elapsed_time(e1) / reps * 1e-3) / 1e12)
-        print(f"{name:24s} " + " ".join(f"{v:10.1f}" for v in row) + "   us: " +
-              " ".join(f"{flops / (v * 1e12) * 1e6:8.1f}" for v in row), flush=True)
-        del t
-        torch.cuda.empty_cache()
-
-
 def main():
     what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["denorm", "acc", "time"]
-    if what[0] == "vtime":
-        return vtime(what[1:] or list(VARIANTS))
     if "denorm" in what:
         denorm()
     print("activation pre-scale of this build:", ops._s16_act_scale())
