@@ -61,10 +61,15 @@ static_assert(p_wait(K_FIRST, 2, true, true) < 64 && p_wait(K_LAST, 2, true, tru
 
 template <int V>
 using ic = std::integral_constant<int, V>;
+
 }  // namespace
 
-template <bool ASCALE, bool HAS_RES>
+// HAS_SKIP: the fused 1x1 shortcut of a ResnetBlock (models.py:109,128-132) as extra K chunks at the centre tap, between a
+// tile's LAST chunk and its register epilogue -- in the halo / weight buffers the chunk stream is not using at that moment
+// (the other halo buffer holds the next tile's first chunk, weight buffers 0 / 1 its first two tiles).
+template <bool ASCALE, bool HAS_RES, bool HAS_SKIP = false>
 __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(const ConvArgs p, const int total) {
+    static_assert(!HAS_SKIP || (ASCALE && !HAS_RES), "a fused shortcut reads a raw operand (bound required) and replaces the residual");
     constexpr int WM = P_WM, WN = P_WN, MT = P_MT, NT = P_NT, BN = P_BN, HR = P_HR, HSPLIT = P_HSPLIT, LDH = P_LDH, KCH = P_KCH;
     constexpr int MAXH = P_MAXH, HWd = P_HWD, NWB = P_NWB, WTILE = P_WTILE, BR = P_BR, NTHREADS = P_NTHREADS;
     __shared__ __attribute__((aligned(1024))) char lds_all[NWB * WTILE + P_HBYTES + WM * BN * 2 * 4];
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             cs[j] = cq[j] = 0.f;
-            const float add = addv[j][0] + addv[j][1];
+            const float add = addv[j][0];            // bias + per-sample addend (summed at the LAST chunk's tap 4)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -392,6 +397,10 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
                     addv[j][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_badd, c_lane + j * 128, (unsigned)((t_img * d.badd_stride + t_ntile * BN) * 4), 0));
                 }
             }
+            if constexpr (tap == 4) {              // (requested four taps ago: no wait to speak of; frees two registers)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) addv[j][0] = addv[j][0] + addv[j][1];
+            }
             if constexpr (HAS_RES) {
 #pragma unroll
                 for (int k = p_first_of(tap); k < p_first_of(tap + 1); ++k)
@@ -415,6 +424,64 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
         hb ^= 1;
     };
 
+    // ---- fused 1x1 shortcut (HAS_SKIP): thread -> (float4 column sc of 8, interior pixels srow + 64 i) of the raw input,
+    // staged at the pixel's halo position so that the centre tap reads it; its [128][hi 32 | lo 32] weight tile arrives by
+    // LDS-DMA like the main ones (same swizzled image; the one-tile kernel stages it through registers)
+    constexpr int SR = 4;
+    const int sc8 = tid & 7, srow = tid >> 3;
+    int s_img = 0, s_ty0 = 0, s_tx0 = 0;
+    f32x4 s_st[SR];
+    const int SCin = d.SC0 + d.SC1;
+    const unsigned sw_rowlen = (unsigned)SCin * 4u;
+    const __amdgpu_buffer_rsrc_t r_sw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(reinterpret_cast<const void*>(d.skip_weight)), 0, HAS_SKIP ? (unsigned)p.n_tiles * BN * sw_rowlen : 0u, 0x00020000);
+    const unsigned sw_lane = (unsigned)(wave * 8 + lrow) * sw_rowlen + (unsigned)((lpiece ^ wswz) * 16);
+    unsigned sw_soff = 0;
+    auto skip_setup = [&](int img, int ty0, int tx0, int ntile) {      // the tile that has just finished its LAST chunk
+        s_img = img;
+        s_ty0 = ty0;
+        s_tx0 = tx0;
+        sw_soff = (unsigned)ntile * BN * sw_rowlen;
+    };
+    auto skip_prefetch = [&](int ch) {
+        const int cb = ch * KCH;
+        const float* src;
+        int cs, coff;
+        if (cb < d.SC0) { src = d.skip0; cs = d.SC0; coff = cb; }
+        else { src = d.skip1; cs = d.SC1; coff = cb - d.SC0; }
+#pragma unroll
+        for (int i = 0; i < SR; ++i) {
+            const int m = srow + 64 * i;
+            const int so = (s_img * p.Hs + s_ty0 + (m >> 5)) * p.Ws + s_tx0 + (m & 31);
+            s_st[i] = *reinterpret_cast<const f32x4*>(src + (size_t)so * cs + coff + sc8 * 4);
+        }
+    };
+    auto skip_issue_w = [&](int ch) {                // weight tile of shortcut chunk `ch` -> weight buffer 2
+        char* dst = Bs + 2 * WTILE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_sw, (__attribute__((address_space(3))) void*)(dst + j * (NTHREADS / 64) * 1024), 16,
+                                                     sw_lane, sw_soff + (unsigned)ch * KCH * 4u + (unsigned)j * (NTHREADS / 8) * sw_rowlen, 0, 0);
+    };
+    auto skip_phase = [&](int hbuf, float ascale_cur, int img, int ty0, int tx0, int ntile) {
+        const int nsk = SCin / KCH;
+        skip_setup(img, ty0, tx0, ntile);
+        skip_prefetch(0);
+        for (int ch = 0; ch < nsk; ++ch) {
+            __syncthreads();                          // everybody is done with the previous reads of these two buffers
+            skip_issue_w(ch);
+#pragma unroll
+            for (int i = 0; i < SR; ++i) {
+                const int m = srow + 64 * i;
+                split_store(&Hs[hbuf * MAXH * LDH + (((m >> 5) + 1) * HWd + (m & 31) + 1) * LDH + sc8 * 4], s_st[i], ascale_cur);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the weight tile have landed
+            __syncthreads();
+            if (ch + 1 < nsk) skip_prefetch(ch + 1);
+            mfma_tap(4, 2, hbuf);
+        }
+    };
+
     bool pending = false;
     for (;;) {
         int c0 = 0;
@@ -427,6 +494,8 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
         const int vn = v + G;
         have_next = vn < total;
         const int c_img = t_img, c_ntile = t_ntile;
+        const float ascale_cur = ascale_stage;
+        const int c_ty0 = t_ty0, c_tx0 = t_tx0;
         if (have_next) {
             tile_of(vn);
             set_hoff();
@@ -444,6 +513,7 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
             t_img = n_img;
             t_ntile = n_ntile;
         }
+        if constexpr (HAS_SKIP) skip_phase(hb ^ 1, ascale_cur, c_img, c_ty0, c_tx0, c_ntile);      // run_chunk toggled hb: hb = the next tile's halo, hb ^ 1 is free
         finalize();
         if (!have_next) break;
         v = vn;
@@ -459,11 +529,12 @@ __global__ __launch_bounds__(P_NTHREADS, 1) void conv3x3_s16_persist_kernel(cons
     for (int k = 0; k < P_NOUT; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv[k]), r_out, o_lane, o_soff(pend_base, k), 0);
 }
 
-// Launches of at least two tiles per CU, 32-pixel-wide patches, no fused shortcut / upsampled residual / split-K.
+// Launches of at least two tiles per CU, 32-pixel-wide patches, no upsampled residual / split-K.
 bool conv3x3_s16_persist_eligible(const ConvArgs& p) {
     const ddnm_conv_desc& d = p.d;
     const long tiles = (long)p.m_tiles * p.n_tiles;
-    return p.ksplit == 1 && tiles >= 512 && p.TW == 32 && !d.res_ups && !d.skip0 && !d.out_nchw && p.Cin / P_KCH >= 2 &&
+    if (d.skip0 && (!d.amax_in || d.res)) return false;        // (the only fused-shortcut instance: raw shortcut operand, no residual)
+    return p.ksplit == 1 && tiles >= 512 && p.TW == 32 && !d.res_ups && !d.out_nchw && p.Cin / P_KCH >= 2 &&
            (int64_t)d.B * d.Ho * d.Wo * d.Cout * 4 < ((int64_t)1 << 31) && (int64_t)p.m_tiles * d.Cout * 8 < ((int64_t)1 << 31);
 }
 
@@ -475,7 +546,8 @@ int conv3x3_s16_persist_launch(const ConvArgs& p, hipStream_t s) {
     cus -= cus % 8;                                     // the XCD-contiguous tile order wants a multiple of 8 workgroups
     const dim3 grid(total < cus ? total : cus);
     const bool asc = p.d.amax_in != nullptr, res = p.d.res != nullptr;
-    if (asc && res) { DDNM_LAUNCH((conv3x3_s16_persist_kernel<true, true>), grid, dim3(P_NTHREADS), 0, s, p, total); }
+    if (p.d.skip0) { DDNM_LAUNCH((conv3x3_s16_persist_kernel<true, false, true>), grid, dim3(P_NTHREADS), 0, s, p, total); }
+    else if (asc && res) { DDNM_LAUNCH((conv3x3_s16_persist_kernel<true, true>), grid, dim3(P_NTHREADS), 0, s, p, total); }
     else if (asc) { DDNM_LAUNCH((conv3x3_s16_persist_kernel<true, false>), grid, dim3(P_NTHREADS), 0, s, p, total); }
     else if (res) { DDNM_LAUNCH((conv3x3_s16_persist_kernel<false, true>), grid, dim3(P_NTHREADS), 0, s, p, total); }
     else { DDNM_LAUNCH((conv3x3_s16_persist_kernel<false, false>), grid, dim3(P_NTHREADS), 0, s, p, total); }

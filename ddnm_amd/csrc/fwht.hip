@@ -75,6 +75,95 @@ __global__ __launch_bounds__(256) void fwht_cols_kernel(const float* __restrict_
     for (int r = ty; r < n; r += 8) dst[(size_t)r * n + tx] = tile[r * (CS + 1) + tx] * scale;
 }
 
+// ---- cols pass, register-resident (round 6; n >= 64): the strip's log2(n) butterfly stages used to be log2(n) read-modify-
+// write passes over an LDS image with a barrier each (16 for the masked form: 0.05 ... 0.10 of the byte floor).  Here a thread
+// (column tx, row group ty of 8) holds n / 8 CONSECUTIVE rows of its column in registers: the low log2(n / 8) stages are
+// register arithmetic, ONE transposition through LDS regroups the strip so that the same thread holds rows r + (n / 8) k,
+// k = 0..7, and the top three stages are register arithmetic again.  The masked form multiplies by the mask in that layout
+// (the mask is read once, coalesced) and runs the second transform the same way (back to consecutive rows, low stages, top
+// stages): three barriers instead of sixteen, LDS traffic 6 x the strip instead of 32 x.  Same additions in the same order
+// per element as the stage-by-stage kernel (the stages of a transform are NOT reordered): bit-identical results.
+template <int N, bool MASKED>
+__global__ __launch_bounds__(256) void fwht_cols_reg_kernel(const float* __restrict__ in, const float* __restrict__ mask,
+                                                            int planes_mask, float* __restrict__ out, float scale) {
+    constexpr int RPT = N / 8, Q = RPT / 8;          // rows per thread; cross-phase row slots per thread
+    static_assert(Q >= 1, "n >= 64");
+    __shared__ float tile[N * (CS + 1)];
+    constexpr int strips = N / CS;
+    const int plane = blockIdx.x / strips, strip = blockIdx.x - plane * strips;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (size_t)plane * N * N + strip * CS + tx;
+    float* dst = out + (size_t)plane * N * N + strip * CS + tx;
+    float v[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) v[i] = src[(size_t)(ty * RPT + i) * N];
+    auto low = [&]() {                                // stages h = 1 .. RPT / 2 over the thread's consecutive rows
+#pragma unroll
+        for (int h = 1; h < RPT; h <<= 1)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+                if (!(i & h)) { const float a = v[i], b = v[i + h]; v[i] = a + b; v[i + h] = a - b; }
+    };
+    auto cross = [&]() {                              // stages h = RPT, 2 RPT, 4 RPT: v[j * 8 + k] = row (ty Q + j) + RPT k
+#pragma unroll
+        for (int h = 1; h < 8; h <<= 1)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+                if (!((i & 7) & h)) { const float a = v[i], b = v[i + h]; v[i] = a + b; v[i + h] = a - b; }
+    };
+    low();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) tile[(ty * RPT + i) * (CS + 1) + tx] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[j * 8 + k] = tile[(ty * Q + j + RPT * k) * (CS + 1) + tx];
+    cross();
+    if constexpr (MASKED) {
+        const float* m = mask + (size_t)(plane % planes_mask) * N * N + strip * CS + tx;
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j * 8 + k] *= m[(size_t)(ty * Q + j + RPT * k) * N];
+        // second transform: its low stages need the consecutive-row layout again.  H is applied stage by stage in ascending
+        // order like the first one: low stages first -- so back through LDS, low(), and through LDS once more for the top
+        // three.  (The stages commute mathematically, but not in floating point: the reference order is kept.)
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tile[(ty * Q + j + RPT * k) * (CS + 1) + tx] = v[j * 8 + k];      // own slots: no hazard
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) v[i] = tile[(ty * RPT + i) * (CS + 1) + tx];
+        low();
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) tile[(ty * RPT + i) * (CS + 1) + tx] = v[i];      // own slots again
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[j * 8 + k] = tile[(ty * Q + j + RPT * k) * (CS + 1) + tx];
+        cross();
+    }
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[(size_t)(ty * Q + j + RPT * k) * N] = v[j * 8 + k] * scale;
+}
+
+template <bool MASKED>
+static int launch_cols(const float* in, const float* mask, int planes_mask, float* out, int planes, int n, float scale, hipStream_t s) {
+    const dim3 grid(planes * (n / CS));
+    switch (n) {
+        case 256: DDNM_LAUNCH((fwht_cols_reg_kernel<256, MASKED>), grid, dim3(256), 0, s, in, mask, planes_mask, out, scale); break;
+        case 128: DDNM_LAUNCH((fwht_cols_reg_kernel<128, MASKED>), grid, dim3(256), 0, s, in, mask, planes_mask, out, scale); break;
+        case 64: DDNM_LAUNCH((fwht_cols_reg_kernel<64, MASKED>), grid, dim3(256), 0, s, in, mask, planes_mask, out, scale); break;
+        default: DDNM_LAUNCH(fwht_cols_kernel<MASKED>, grid, dim3(256), n * (CS + 1) * sizeof(float), s, in, mask, planes_mask, out, n, scale);
+    }
+    return 0;
+}
+
 static bool fwht_n_ok(int n) { return n == 32 || n == 64 || n == 128 || n == 256; }
 
 extern "C" int ddnm_fwht2d_f32(const float* in, float* out, int32_t planes, int32_t n, void* stream) {
@@ -85,9 +174,7 @@ extern "C" int ddnm_fwht2d_f32(const float* in, float* out, int32_t planes, int3
     const int rows_per_block = 4 * (64 / (n / 4));
     DDNM_LAUNCH(fwht_rows_kernel, dim3((unsigned)((rows + rows_per_block - 1) / rows_per_block)), dim3(256), 0,
                        s, in, out, n, rows, 1.0f);
-    DDNM_LAUNCH(fwht_cols_kernel<false>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
-                       out, nullptr, 1, out, n, 1.0f / (float)n);
-    return 0;
+    return launch_cols<false>(out, nullptr, 1, out, planes, n, 1.0f / (float)n, s);
 }
 
 extern "C" int ddnm_fwht2d_masked_f32(const float* in, const float* mask, int32_t planes_mask, float* out,
@@ -100,8 +187,7 @@ extern "C" int ddnm_fwht2d_masked_f32(const float* in, const float* mask, int32_
     const dim3 grid_rows((unsigned)((rows + rows_per_block - 1) / rows_per_block));
     // H in (unnormalised rows), then cols-mask-cols with the forward 1/n, then rows with the inverse 1/n
     DDNM_LAUNCH(fwht_rows_kernel, grid_rows, dim3(256), 0, s, in, scratch, n, rows, 1.0f);
-    DDNM_LAUNCH(fwht_cols_kernel<true>, dim3(planes * (n / CS)), dim3(256), n * (CS + 1) * sizeof(float), s,
-                       scratch, mask, planes_mask, scratch, n, 1.0f / (float)n);
+    { const int rc = launch_cols<true>(scratch, mask, planes_mask, scratch, planes, n, 1.0f / (float)n, s); if (rc) return rc; }
     DDNM_LAUNCH(fwht_rows_kernel, grid_rows, dim3(256), 0, s, scratch, out, n, rows, 1.0f / (float)n);
     return 0;
 }

@@ -128,7 +128,7 @@ def test_micro_batched_forward_beyond_one_launch(hip, adm_full_fp16):
     cm = Model(ccfg)
     cm.load_state_dict(cm.random_state_dict(3))
     mb = cm.max_forward_batch
-    assert mb == 16
+    assert mb == 32
     x = torch.randn(72, 3, 256, 256, generator=g).cuda()
     t = torch.full((72,), 430.0).cuda()
     whole = cm(x, t)

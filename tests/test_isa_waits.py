@@ -113,9 +113,19 @@ def test_persistent_kernel_waits_match_the_issue_order_on_every_path(tmp_path):
     stores, residual / bias / bound loads and the statistics store included), and the immediates are the source's table."""
     asm = isa_waits.compile_isa(os.path.join(CSRC, "conv_s16_persist.hip"), str(tmp_path / "p.s"))
     res = isa_waits.analyse_cfg(asm, r"conv3x3_s16_persist_kernel", depth=2, group_size=2)
-    assert len(res) == 4, list(res)
+    assert len(res) == 5, list(res)          # <ASCALE, HAS_RES> x 4 + the fused-shortcut instance <true, false, true>
     for name, waits in res.items():
-        ascale, has_res = "ILb1E" in name, ("ELb1EEv" in name)
+        m = re.search(r"kernelILb(\d)ELb(\d)ELb(\d)E", name)
+        ascale, has_res, has_skip = (g == "1" for g in m.groups())
+        tap_waits = [w for w in waits if w[0] > 0]
+        if has_skip:
+            # the shortcut phase (plain loads + its own full waits) sits between a tile's LAST chunk and the next FIRST chunk,
+            # and this instance keeps two spilled LDS addresses in scratch: paths through them see MORE requests behind the
+            # awaited tile than the immediate allows in flight -- an over-wait (VMEM retires in order), never a stale tile.
+            # Demanded: no path with fewer, and the tight path exists.
+            for n, found, line in tap_waits:
+                assert min(found) == n, f"{name}: wait vmcnt({n}) at line {line}: paths = {found}"
+            continue
         assert len(waits) == 27, (name, len(waits))                 # 3 chunk kinds x 9 taps, each exactly once in the code
         for n, found, line in waits:
             assert found == [n], f"{name}: wait vmcnt({n}) at line {line}: requests behind the awaited tile on the paths = {found}"

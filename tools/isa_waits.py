@@ -291,8 +291,9 @@ def _block_events(lines, s, e):
 
 
 def analyse_cfg(asm, name_re, depth, group_size):
-    """{kernel: [(N, sorted set of request counts found behind the awaited DMA group over all paths), ...]} for every
-    `s_waitcnt vmcnt(N) lgkmcnt(0)` (N > 0) that directly precedes an s_barrier."""
+    """{kernel: [(N, sorted set of request counts found behind the awaited DMA group over all paths, line), ...]} for every
+    `s_waitcnt vmcnt(N) lgkmcnt(0)` (N > 0) that directly precedes an s_barrier.  A count ABOVE N on some path is an
+    over-wait there (safe: VMEM retires in order), a count BELOW N a stale tile; 64 stands for "more than vmcnt counts"."""
     out = {}
     for name, lines in kernels(asm).items():
         if not re.search(name_re, name):
@@ -336,8 +337,11 @@ def analyse_cfg(asm, name_re, depth, group_size):
                         idx -= 1
                     if done:
                         continue
-                    if behind > 200:
-                        raise AssertionError(f"{name}: no DMA group within 200 requests of the wait at line {val[2]}")
+                    if behind > 64:
+                        # more requests than vmcnt can count (a loop of plain loads between the DMA groups, e.g. the fused
+                        # shortcut phase of the persistent kernel): recorded as "> 63", i.e. an over-wait on that path
+                        found.add(64)
+                        continue
                     for pb in pred[bb]:
                         stack.append((pb, len(evs[pb]) - 1, g, ing, behind))
                     # (a path that reaches the kernel entry without `depth` groups does not exist for these kernels: the

@@ -19,20 +19,25 @@ SHAPES = [s for s in sp.SHAPES if s[0] in ("c128_128_256_gn_res", "c128_128_256_
     ("c128_128_256_b3", 3, 128, 0, 128, 256, 0, 1, 1, 0),           # 768 tiles: 3 per workgroup
     ("c64_128_256_b2", 2, 64, 0, 128, 256, 0, 1, 1, 0),             # two chunks: FIRST directly followed by LAST
     ("c96cat_128_256_b2", 2, 64, 32, 128, 256, 0, 1, 0, 0),
+    ("c128_128_256_gn_skip", 8, 128, 0, 128, 256, 0, 1, 0, 1),      # fused 1x1 shortcut (64 raw channels)
+    ("c128_256_128_gn_skip_b4", 4, 128, 0, 256, 128, 0, 1, 0, 1),    # two channel tiles
     ("c128_128_256_b1", 1, 128, 0, 128, 256, 0, 1, 1, 0),           # 256 tiles: not eligible, both paths the same kernel
 ]
 
 
 def call(t, one_tile):
-    scale = ops.s16_weight_scale(t["w"])
-    s16 = (ops.pack_conv_weight_s16(t["w"], scale), scale, None)
+    ws = [t["w"]] + ([t["wsk"]] if t["wsk"] is not None else [])
+    scale = ops.s16_weight_scale(*ws)
+    s16 = (ops.pack_conv_weight_s16(t["w"], scale), scale, ops.pack_conv_weight_s16(t["wsk"], scale) if t["wsk"] is not None else None)
     w32 = ops.pack_conv_weight(t["w"])
+    wsk32 = ops.pack_skip_weight(t["wsk"]) if t["wsk"] is not None else None
     gn = None if t["sc"] is None else (t["sc"], t["sh"])
     badd = t["badd"]
 
     def f():
         return ops.conv2d(t["a"], w32, t["Cout"], 3, src1=t["b"], bias=t["bias"], badd=badd, badd_stride=badd.shape[1], res=t["r"], gn=gn,
-                          gn_silu=True, ups=bool(t["ups"]), emit_stats=True, weight_s16=s16, one_tile=one_tile, raw_amax=t["amax"])
+                          gn_silu=True, ups=bool(t["ups"]), emit_stats=True, weight_s16=s16, one_tile=one_tile, raw_amax=t["amax"],
+                          skip=None if t["sk"] is None else (t["sk"], None), skip_weight=wsk32)
     return f
 
 
@@ -42,9 +47,9 @@ def main():
         name, B, C0, C1, Cout = s[:5]
         t = sp.make(*s)
         t["badd"] = torch.randn(B, Cout, device="cuda")
-        t["amax"] = None if s[7] else ops.amax_bound(t["a"], t["b"])
+        t["amax"] = ops.amax_bound(t["sk"]) if s[9] else (None if s[7] else ops.amax_bound(t["a"], t["b"]))
         Ho = t["Ho"]
-        flops = 2.0 * B * Ho * Ho * Cout * 9 * (C0 + C1)
+        flops = 2.0 * B * Ho * Ho * Cout * (9 * (C0 + C1) + (64 if s[9] else 0))
         res, us = {}, {}
         for one in (True, False):
             f = call(t, one)
