@@ -197,6 +197,8 @@ PROTOTYPES = {
                                        c_int32, c_void_p]),
     "ddnm_mul_planes_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p]),
     "ddnm_fill_f32": (c_int32, [c_void_p, c_int64, c_float, c_void_p]),
+    "ddnm_attn_fused_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p]),
+    "ddnm_attn_fused_supported": (c_int32, [c_int32, c_int32]),
     "ddnm_randn_philox_f32": (c_int32, [c_void_p, c_int32, c_int64, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
     "ddnm_renoise_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ddnm_op_avgpool_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddnm_hip.so")
 STAMP = os.path.join(HERE, ".libddnm_hip.stamp")
 OBJ = os.path.join(HERE, "_obj")
-SOURCES = ["conv_igemm_f32.hip", "conv_igemm_f16.hip", "conv_s16_persist.hip", "conv_gather_s16.hip", "conv_small_f32.hip", "conv1x1_f16.hip", "conv16.hip", "act16.hip", "attn16.hip", "attn16_bwd.hip", "gemm_f32.hip", "groupnorm.hip", "misc.hip", "ddnm_step.hip", "fwht.hip", "backward.hip"]
+SOURCES = ["conv_igemm_f32.hip", "conv_igemm_f16.hip", "conv_s16_persist.hip", "conv_gather_s16.hip", "conv_small_f32.hip", "conv1x1_f16.hip", "conv16.hip", "act16.hip", "attn16.hip", "attn_d512.hip", "attn16_bwd.hip", "gemm_f32.hip", "groupnorm.hip", "misc.hip", "ddnm_step.hip", "fwht.hip", "backward.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

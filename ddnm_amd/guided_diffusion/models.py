@@ -56,6 +56,9 @@ class Model:
         """`split16`: run the 3x3 / stride-1 layers on the split-fp16 kernel (None: the DDNM_CONV_F32 default above)."""
         self.config = config
         self.split16 = SPLIT16 if split16 is None else bool(split16)
+        self.fused_attn = self.split16        # AttnBlock in one launch (csrc/attn_d512.hip, split-fp16 products); the strict
+        #                                       fp32 engine keeps the three-launch fp32-MFMA route
+        self.fused_attn_max_tokens = 64       # measured: 26.0 -> 17.4 us at T = 64, but 42.1 -> 50.7 us at T = 256 (B = 8)
         m = config.model
         self.ch, self.out_ch, self.ch_mult = m.ch, m.out_ch, tuple(m.ch_mult)
         self.num_res_blocks = m.num_res_blocks
@@ -264,6 +267,17 @@ class Model:
                 w[f"{n}.qkv.s16"] = s16(wq)
                 w[f"{n}.proj_out.s16"] = s16(g(f"{n}.proj_out.weight"))
             w[f"{n}.qkv.bias"] = torch.cat([g(f"{n}.{p}.bias") for p in ("q", "k", "v")], 0).contiguous()
+            # operand scales of the fused attention kernel (split-fp16 products need |operand| < 2^15): a STATIC bound of the
+            # 1x1 convolutions' outputs, |W . GN(x) + b| <= max_o sum_c |W[o, c]| * (sqrt(n) max|gamma| + max|beta|) + max|b|
+            # over the n = H*W*C/32 elements of a group (the bound _guard_normalised_operands uses), as powers of two
+            gmax = math.sqrt(a.res * a.res * max(1, a.c // 32)) * float(sd[f"{n}.norm.weight"].detach().abs().max()) + \
+                float(sd[f"{n}.norm.bias"].detach().abs().max())
+
+            def _pow2(*names):
+                bnd = max(float(sd[f"{n}.{p}.weight"].detach().float().abs().flatten(1).sum(1).max()) * gmax +
+                          float(sd[f"{n}.{p}.bias"].detach().abs().max()) for p in names)
+                return 2.0 ** (14 - math.ceil(math.log2(max(bnd, 1e-30))))
+            w[f"{n}.attn_scales"] = (_pow2("q", "k"), _pow2("v"))
             w[f"{n}.proj_out.weight"] = ops.pack_conv_weight(g(f"{n}.proj_out.weight"))
             w[f"{n}.proj_out.bias"] = g(f"{n}.proj_out.bias")
         for lvl, (_, _, has_down, c) in enumerate(self.down):
@@ -387,6 +401,12 @@ class Model:
         gn = self._gn(x, None, n + ".norm")
         qkv = ops.conv2d(x, w[n + ".qkv.weight"], 3 * C, 1, gn=gn, gn_silu=False, bias=w[n + ".qkv.bias"],
                          weight_s16=w.get(n + ".qkv.s16"))
+        sc = w.get(n + ".attn_scales")
+        if sc is not None and self.fused_attn and T <= self.fused_attn_max_tokens and ops.attn_fused_supported(T, C):
+            # one launch, no [T][T] tensor in HBM (csrc/attn_d512.hip)
+            o = ops.attn_fused(qkv, B, T, C, sc[0], sc[1], float(int(C) ** (-0.5))).view(B, H, W, C)
+            return ops.conv2d(o, w[n + ".proj_out.weight"], C, 1, bias=w[n + ".proj_out.bias"], res=x, emit_stats=True,
+                              weight_s16=w.get(n + ".proj_out.s16"))
         S = torch.empty(B, T, T, dtype=torch.float32, device=qkv.device)
         q, k, v = qkv.view(-1)[0:], qkv.view(-1)[C:], qkv.view(-1)[2 * C:]
         ops.bgemm(q, k, S, T, T, C, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B,

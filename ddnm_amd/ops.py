@@ -701,6 +701,21 @@ def bgemm(A, Bm, C, M, N, K, *, lda, ldb, ldc, transb, batch=1, inner=1, sA=(0, 
     return C
 
 
+def attn_fused_supported(T, C):
+    return _lib.lib().ddnm_attn_fused_supported(int(T), int(C)) == 1
+
+
+def attn_fused(qkv, B, T, C, s_qk, s_v, scale, out=None):
+    """Single-head self-attention over qkv [B, T, 3C] fp32 (q | k | v per token) in ONE launch (csrc/attn_d512.hip): the two
+    torch.bmm and the softmax of guided_diffusion/models.py:171-185.  s_qk / s_v: power-of-two operand scales (see
+    models.Model: a static bound per checkpoint)."""
+    if out is None:
+        out = torch.empty(B, T, C, dtype=torch.float32, device=qkv.device)
+    check(_lib.lib().ddnm_attn_fused_f32(_p(_f32c(qkv, "qkv")), _p(out), B, T, C, float(s_qk), float(s_v), float(scale), _stream()),
+          "ddnm_attn_fused_f32")
+    return out
+
+
 def softmax_rows_(x, rows, n, ld, scale):
     check(_lib.lib().ddnm_softmax_rows_f32(_p(x), rows, n, ld, scale, _stream()), "ddnm_softmax_rows_f32")
     return x

@@ -378,6 +378,17 @@ int ddnm_pool_tokens_h16(const void* h, const float* gn_scale, const float* gn_s
                          float* X /* [B][HW+1][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
 int ddnm_pool_tokens_bwd_h16(const float* dX, void* dact /* fp16 [B][HW][C] */, int32_t B, int32_t HW, int32_t C, void* stream);
 
+/* ABI 7 -- fused single-head self-attention of the celeba `Model`'s AttnBlock (guided_diffusion/models.py:171-185: the two
+ * torch.bmm and the softmax between them): qkv = [B][T][3C] fp32 (q | k | v per token, the output of the fused
+ * q / k / v 1x1 convolution), out = [B][T][C] fp32 = softmax_j(q_i . k_j * softmax_scale) v_j.  No [T][T] tensor in HBM.
+ * Split-fp16 products (hi*hi' + hi*lo' + lo*hi', fp32 accumulate) like ddnm_conv3x3_s16_f32; s_qk / s_v = powers of two with
+ * max|q|, max|k| <= 2^15 / s_qk and max|v| <= 2^15 / s_v (the host derives them once per checkpoint from a static bound of the
+ * convolution's output; scores / outputs are multiplied by the inverse powers: exact).  T % 32 == 0, T <= 256, C % 128 == 0,
+ * C <= 512. */
+int ddnm_attn_fused_f32(const float* qkv, float* out, int32_t B, int32_t T, int32_t C, float s_qk, float s_v,
+                        float softmax_scale, void* stream);
+int ddnm_attn_fused_supported(int32_t T, int32_t C);
+
 /* Row softmax in place: x[r][0..n) <- softmax(scale * x[r][:]); rows contiguous with ld. */
 int ddnm_softmax_rows_f32(float* x, int64_t rows, int32_t n, int32_t ld, float scale, void* stream);
 

@@ -459,3 +459,31 @@ def test_conv_in_as_im2col_gemm(hip):
     torch.cuda.synchronize()
     assert rel(out.t.cpu().permute(0, 3, 1, 2), F.conv2d(x, w, b, padding=1)) < 2e-6
     assert out.stats is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,C,mag", [(8, 256, 512, 1.0), (3, 64, 512, 1.0), (2, 256, 256, 40.0), (1, 96, 128, 1e-3)])
+def test_fused_single_head_attention(hip, B, T, C, mag):
+    """ddnm_attn_fused_f32 (csrc/attn_d512.hip; the AttnBlock of guided_diffusion/models.py:171-185 in one launch) against an
+    fp64 evaluation of the reference's formula and against the three-launch route (bgemm -> softmax_rows -> bgemm on the fp32
+    MFMA): fp32 grade, for operand magnitudes far from 1 as well (the power-of-two operand scales)."""
+    import math
+    from ddnm_amd import ops
+    g = torch.Generator().manual_seed(T + C)
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * mag).cuda()
+    qkv[..., :2 * C] *= (4.0 / (mag * C ** 0.25))          # scores of a few units: a softmax that is neither flat nor one-hot
+    q, k, v = (qkv[..., i * C:(i + 1) * C].double() for i in range(3))
+    want = torch.softmax(q @ k.transpose(1, 2) * (int(C) ** (-0.5)), dim=2) @ v
+    bound = lambda t: 2.0 ** (14 - math.ceil(math.log2(float(t.abs().max()) * 37.0)))      # noqa: E731   a loose bound, like the model's
+    got = ops.attn_fused(qkv, B, T, C, bound(qkv[..., :2 * C]), bound(qkv[..., 2 * C:]), float(int(C) ** (-0.5)))
+    S = torch.empty(B, T, T, device="cuda")
+    f = qkv.view(-1)
+    ops.bgemm(f[0:], f[C:], S, T, T, C, lda=3 * C, ldb=3 * C, ldc=T, transb=True, batch=B, sA=(T * 3 * C, 0), sB=(T * 3 * C, 0), sC=(T * T, 0))
+    ops.softmax_rows_(S, B * T, T, T, float(int(C) ** (-0.5)))
+    o3 = torch.empty(B, T, C, device="cuda")
+    ops.bgemm(S, f[2 * C:], o3, T, C, T, lda=T, ldb=3 * C, ldc=C, transb=False, batch=B, sA=(T * T, 0), sB=(T * 3 * C, 0), sC=(T * C, 0))
+    torch.cuda.synchronize()
+    rel = lambda a: ((a.double().cpu() - want.cpu()).norm() / want.cpu().norm()).item()      # noqa: E731
+    e_f, e_3 = rel(got), rel(o3)
+    assert bool(torch.isfinite(got).all())
+    assert e_f < 2e-6 and e_f <= 2.0 * e_3 + 3e-7, (e_f, e_3)
