@@ -640,7 +640,7 @@ def main():
                                       + b_ * ho * wo * cout * (2 if has_res else 1)))
             total_ms = sum(v["ms"] for v in summ.values())
             achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
-            if name.startswith("conv3x3_halo_s16"):
+            if name.startswith("conv3x3_halo_s16") or name.startswith("conv3x3_s16_persist"):
                 peak = PEAK_SPLIT16_TFLOPS
                 peak_note = ("dense fp16 MFMA peak 2500 TFLOP/s / 3: one fp32-grade product = three fp16 MFMA products; "
                              "`achieved` counts algorithmic FLOPs (x3 = %.0f TFLOP/s of MFMA work)" % (3 * achieved))
@@ -670,7 +670,7 @@ def main():
                 "share_of_conv_time": round(r["ms"] / total_ms, 4),
                 # MFMA work actually issued by the dominant kernel: 3 fp16 products per algorithmic product in the split
                 # form (compare THIS with the 2500 TFLOP/s dense fp16 peak; `achieved` with `peak`)
-                "mfma_work_tflops": round(achieved * (3 if name.startswith("conv3x3_halo_s16") else 1), 1),
+                "mfma_work_tflops": round(achieved * (3 if (name.startswith("conv3x3_halo_s16") or name.startswith("conv3x3_s16_persist")) else 1), 1),
                 "whole_loop_tflops": round(value * T_SAMPLING * FLOPS_PER_FWD_PER_IMAGE / 1e12 / world, 2),
                 # the loop holds split-fp16, fp32-MFMA and vector kernels, so its algorithmic rate is quoted against both
                 # fixed peaks by name: the split bound 2500 / 3 and the fp32 MFMA peak 157.3 of rounds 1-2

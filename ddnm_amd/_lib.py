@@ -113,6 +113,7 @@ PROTOTYPES = {
     "ddnm_conv3x3_f16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_f32": (c_int32, [POINTER(ConvDesc), c_void_p]),
     "ddnm_conv3x3_s16_supported": (c_int32, [POINTER(ConvDesc)]),
+    "ddnm_conv3x3_s16_persistent": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_workspace_floats": (c_int64, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_stats_tiles": (c_int32, [POINTER(ConvDesc)]),
     "ddnm_conv3x3_s16_act_scale": (c_float, []),

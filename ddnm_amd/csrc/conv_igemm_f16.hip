@@ -526,6 +526,20 @@ extern "C" int ddnm_conv3x3_s16_f32(const ddnm_conv_desc* d, void* stream) { ret
 
 extern "C" float ddnm_conv3x3_s16_act_scale(void) { return DDNM_S16_ASCALE; }
 
+// 1: this launch would run the persistent form (conv_s16_persist.hip): >= 2 tiles per CU, no split-K (profiling / bench labels)
+extern "C" int ddnm_conv3x3_s16_persistent(const ddnm_conv_desc* d) {
+    PlanF16 pl;
+    if (!d || d->src_f16 || (d->flags & DDNM_CONV_ONE_TILE) || !plan_f16(d, &pl, KC16 / 2) || pl.ksplit != 1) return 0;
+    ConvArgs p;
+    p.d = *d;
+    p.Cin = d->C0 + d->C1;
+    p.m_tiles = d->B * (d->Ho * d->Wo / pl.BM);
+    p.n_tiles = d->Cout / 128;
+    p.TW = pl.TW;
+    p.ksplit = 1;
+    return conv3x3_s16_persist_eligible(p) ? 1 : 0;
+}
+
 extern "C" int ddnm_conv3x3_s16_supported(const ddnm_conv_desc* d) {
     PlanF16 pl;
     return d && !d->src_f16 && plan_f16(d, &pl, KC16 / 2) ? 1 : 0;

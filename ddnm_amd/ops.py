@@ -378,7 +378,7 @@ def conv2d(src0, weight, cout, ksize, *, src1=None, bias=None, badd=None, badd_s
         elif f16:
             variant = "conv3x3_halo_f16<256x128>"
         elif s16:
-            variant = "conv3x3_halo_s16<256x128>"
+            variant = "conv3x3_s16_persist<256x128>" if L.ddnm_conv3x3_s16_persistent(ctypes.byref(d)) == 1 else "conv3x3_halo_s16<256x128>"
         elif s16g:
             variant = "conv_gather_s16"
         else:

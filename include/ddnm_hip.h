@@ -149,6 +149,8 @@ int ddnm_conv3x3_f16_stats_tiles(const ddnm_conv_desc* d);
  * Needs Cin % 32 == 0, C0 % 32 == 0, Cout % 128 == 0, Ho*Wo % 256 == 0 (else: ddnm_conv2d_f32). */
 int ddnm_conv3x3_s16_f32(const ddnm_conv_desc* d, void* stream);
 int ddnm_conv3x3_s16_supported(const ddnm_conv_desc* d);
+int ddnm_conv3x3_s16_persistent(const ddnm_conv_desc* d);   /* ABI 7 -- 1: the launch runs the persistent form (>= 2 tiles per CU: one
+                                                                workgroup per CU walks its tiles; same results bit for bit) */
 int64_t ddnm_conv3x3_s16_workspace_floats(const ddnm_conv_desc* d);
 int ddnm_conv3x3_s16_stats_tiles(const ddnm_conv_desc* d);
 float ddnm_conv3x3_s16_act_scale(void);   /* compile-time activation pre-scale: 1 since ABI 5 (the scale is per launch and

@@ -52,7 +52,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $RAW/hbm/pmc_writ
 cd /root/repo
 python tools/prof_summary.py $(find $RAW/prof_cls -name "*.db" | head -1) gpurun_out/${R}_cls_kernel_stats.md --after-marker finalize_psnr --forwards 5 > /dev/null; head -22 gpurun_out/${R}_cls_kernel_stats.md
 python tools/prof_summary.py $(find $RAW/prof_cls32 -name "*.db" | head -1) gpurun_out/${R}_cls_b32_kernel_stats.md --after-marker finalize_psnr --forwards 3 > /dev/null; head -12 gpurun_out/${R}_cls_b32_kernel_stats.md
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='(?:conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>|conv3x3_s16_persist_kernel)' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/st_c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md | tail -7
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_s16_persist_kernel' PMC_PASSES="2 celeba forwards at B=8 per pass (tools/forward_once.py)" python tools/pmc_stalls.py $RAW/st_c2 gpurun_out/${R}_pmc_stalls_headline.json gpurun_out/${R}_pmc_stalls_headline.md | tail -7
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM fp16 forwards at B=4 per pass (tools/adm_fwd.py)" python tools/pmc_stalls.py $RAW/st_adm gpurun_out/${R}_pmc_stalls_conv16.json gpurun_out/${R}_pmc_stalls_conv16.md | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_n128_kernel' PMC_PASSES="2 classifier-guidance evaluations at B=8 per pass (tools/cls_step.py)" python tools/pmc_stalls.py $RAW/st_cls gpurun_out/${R}_pmc_stalls_n128.json gpurun_out/${R}_pmc_stalls_n128.md | tail -5
 python tools/pmc_hbm_summary.py $RAW/hbm gpurun_out/hbm_kernels_algorithmic.json gpurun_out/${R}_hbm_kernels.json gpurun_out/${R}_hbm_kernels.md | tail -20
@@ -64,7 +64,7 @@ python tools/prof_summary.py $(find $RAW/prof_c2fwd -name "*.db" | head -1) gpur
 python tools/fwd_timeline.py $ADB 5 > gpurun_out/${R}_adm_timeline.txt; tail -1 gpurun_out/${R}_adm_timeline.txt
 # dominant kernel of the headline workload: the split-fp16 form of the 3x3 halo kernel (template arguments .., SRC16 = false,
 # SPLIT = true, ASCALE = either) and its persistent form
-PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='(?:conv3x3_halo_f16_kernel<4, 2, 2, 2, false, true, (?:false|true)>|conv3x3_s16_persist_kernel)' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
+PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv3x3_s16_persist_kernel' python tools/pmc_summary.py $RAW/pmc_c2 gpurun_out/${R}_pmc_dominant_kernel.json gpurun_out/${R}_pmc_dominant_kernel.md $BDB | tail -8
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=4 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16 gpurun_out/${R}_adm_pmc_conv16.json gpurun_out/${R}_adm_pmc_conv16.md $ADB | tail -8
 B8DB=$(find $RAW/prof_adm16b8 -name "*.db" | head -1)
 PMC_AFTER_MARKER=finalize_psnr PMC_KERNEL_RE='conv16_kernel<9, [24], 4>' PMC_PASSES="2 ADM forwards (fp16 path) at B=8 per PMC pass, forwards only" python tools/pmc_summary.py $RAW/pmc16b8 gpurun_out/${R}_adm_pmc_conv16_b8.json gpurun_out/${R}_adm_pmc_conv16_b8.md $B8DB | tail -4
